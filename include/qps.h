@@ -1,0 +1,156 @@
+/*
+ * qps.h -- C ABI of the MI355X-native ADMM QP solver (libqps_hip.so).
+ *
+ * Drop-in boundary for ONE path of RoyiAvital/QuadraticProgramSolver (citations are file:line under the
+ * reference repository):
+ *
+ *   SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, LinSysSolInit, LinSysSol!; kw...) -> ConvergenceFlag
+ *                                                     SolveQuadraticProgram.jl:14-76   -> qps_create_* + qps_solve
+ *   CheckConvergence(...)                             SolveQuadraticProgram.jl:79-112  -> inside qps_solve (device)
+ *   LinSysSolInit(vX,mP,vQ,mA,rho,rho1,sigma,n,m)     LinearSystemSolvers.jl:16,47,78,110,145 -> qps_linsys_init
+ *   LinSysSol!(tuSolver,vXX,vZZ,vX,...,changedRho)    LinearSystemSolvers.jl:28,59,91,125,164 -> qps_linsys_solve
+ *   @enum ConvergenceFlag                             SolveQuadraticProgram.jl:12      -> qps_conv_flag
+ *
+ * Everything crossing this boundary is a plain pointer, size or scalar.  Host arrays stay owned by the caller and may
+ * be freed as soon as the call that received them returns (qps_create_* copies the problem into HBM).
+ * A handle is bound to one device and one HIP stream; distinct handles may be driven from distinct host threads, a
+ * single handle is not thread-safe.  All functions return a qps_status (0 = ok).
+ */
+#ifndef QPS_H
+#define QPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPS_VERSION_MAJOR 0
+#define QPS_VERSION_MINOR 1
+
+typedef struct qps_solver_s *qps_handle;
+
+typedef enum {
+    QPS_OK = 0,
+    QPS_ERR_BAD_ARGUMENT = 1,     /* null pointer, negative size, unknown enum value                             */
+    QPS_ERR_BAD_DIMENSION = 2,    /* mirrors the dimension checks of SolveQuadraticProgram.m:158-184             */
+    QPS_ERR_NOT_FINITE = 3,       /* NaN/Inf in P, q, A or NaN in l/u (l,u may be +-Inf)                         */
+    QPS_ERR_FACTORIZATION = 4,    /* Cholesky breakdown (non-positive pivot); qps_last_error names the column    */
+    QPS_ERR_HIP = 5,              /* a HIP runtime call failed; qps_last_error carries hipGetErrorString         */
+    QPS_ERR_OUT_OF_MEMORY = 6,
+    QPS_ERR_NO_DEVICE = 7,        /* no gfx950 device visible: the library never falls back to the CPU           */
+    QPS_ERR_UNSUPPORTED = 8
+} qps_status;
+
+/* SolveQuadraticProgram.jl:12  @enum ConvergenceFlag convNumItr = 1 convAdmm convPrimDual */
+typedef enum { QPS_CONV_NUM_ITR = 1, QPS_CONV_ADMM = 2, QPS_CONV_PRIM_DUAL = 3 } qps_conv_flag;
+
+/* arithmetic type of the device-resident loop */
+typedef enum { QPS_F64 = 0, QPS_F32 = 1 } qps_dtype;
+
+/* which linear-system path replaces the reference plugin pair */
+typedef enum {
+    QPS_LINSYS_AUTO = 0,        /* dense handle -> QPS_LINSYS_CHOLESKY, CSC handle -> QPS_LINSYS_CG                */
+    QPS_LINSYS_CHOLESKY = 1,    /* reduced form P + sigma I + rho A'A, one Cholesky + two triangular sweeps / it   */
+    QPS_LINSYS_CG = 2           /* matrix-free CG on the reduced operator (LinearSystemSolvers.jl:145-186)         */
+} qps_linsys_kind;
+
+/* Keyword arguments of SolveQuadraticProgram! (SolveQuadraticProgram.jl:15-17), same names, same defaults.
+ * delta, numItrPolish, epsMinres, numItrMinres are accepted and ignored exactly as the reference does. */
+typedef struct {
+    int32_t numIterations;   /* 5000 */
+    int32_t adptRho;         /* adptΡ, 0/1, default 0 */
+    int32_t numItrConv;      /* 25 */
+    int32_t numItrPolish;    /* 10 (ignored) */
+    int32_t numItrMinres;    /* 500 (ignored) */
+    int32_t linsys;          /* qps_linsys_kind, additive, default AUTO */
+    int32_t trsvBlock;       /* additive: diagonal-block size of the blocked triangular sweep (0 = library default)   */
+    int32_t reuseFactor;     /* additive: 1 = keep the factorisation of a previous qps_solve/linsys_init when
+                                (rho, sigma) are unchanged; 0 = factorise on every call like the reference (:36)      */
+    double epsAbs;           /* ϵAbs 1e-6 */
+    double epsRel;           /* ϵRel 1e-6 */
+    double rho;              /* ρ 1 */
+    double sigma;            /* σ 1e-6 */
+    double alpha;            /* α 1.6 */
+    double delta;            /* δ 1e-6 (ignored) */
+    double fctrRho;          /* fctrΡ 5 */
+    double epsMinres;        /* ϵMinres 1e-6 (ignored) */
+    double epsPcg;           /* CG plugins' ϵPcg 1e-6 (LinearSystemSolvers.jl:125) */
+    int32_t numItrPcg;       /* CG plugins' numItrPcg 1000 */
+    int32_t reserved;
+} qps_params;
+
+/* Additive out-of-band report (the reference returns only the flag, SolveQuadraticProgram.jl:73). */
+typedef struct {
+    int32_t convFlag;        /* qps_conv_flag */
+    int32_t iterations;      /* loop bodies executed */
+    int32_t numRefactor;     /* changedΡ events (each one re-factorises) */
+    int32_t cgIterations;    /* total inner CG iterations (QPS_LINSYS_CG) */
+    double rhoFinal;         /* ρ in force at exit */
+    double rhoProposed;      /* ρρ at exit */
+    double resPrim;          /* ||A x - z||_inf at the last check (:85) */
+    double resDual;          /* ||P x + q + A'y||_inf at the last check (:86) */
+    double tSetup;           /* seconds: LinSysSolInit (assembly + factorisation), device time incl. sync */
+    double tLoop;            /* seconds: the iteration loop, device time incl. sync */
+    double tRefactor;        /* seconds spent in changedΡ re-factorisations (part of tLoop) */
+} qps_info;
+
+/* Fill *p with the reference defaults (SolveQuadraticProgram.jl:15-17). */
+int32_t qps_default_params(qps_params *p);
+
+/* Number of HIP devices visible (0 when there is none; never an error). */
+int32_t qps_device_count(void);
+
+/* Dense problem, column-major (Julia Matrix{Float64}): P is n x n (leading dimension ldp), A is m x n (lda).
+ * Replaces the data half of the call SolveQuadraticProgram.jl:14 for dense inputs. */
+int32_t qps_create_dense(int64_t n, int64_t m, const double *P, int64_t ldp, const double *A, int64_t lda,
+                         const double *q, const double *l, const double *u, int32_t dtype, int32_t device,
+                         qps_handle *out);
+
+/* Sparse problem, CSC (Julia SparseMatrixCSC{Float64,Int64}: colptr, rowval, nzval), index_base 1 for Julia, 0 for C.
+ * P must hold the full symmetric matrix (as GenerateQuadraticProgram.jl produces).  dense_path != 0 densifies the
+ * problem on the device and uses the Cholesky path; 0 keeps CSR storage and uses the CG path. */
+int32_t qps_create_csc(int64_t n, int64_t m,
+                       const int64_t *P_colptr, const int64_t *P_rowval, const double *P_nzval,
+                       const int64_t *A_colptr, const int64_t *A_rowval, const double *A_nzval,
+                       const double *q, const double *l, const double *u, int32_t index_base, int32_t dense_path,
+                       int32_t dtype, int32_t device, qps_handle *out);
+
+/* SolveQuadraticProgram! (SolveQuadraticProgram.jl:14-76): x_inout is vX (warm start in, solution out, length n);
+ * z and y restart at 0 (:39-40).  info may be NULL.  Blocks until the result is in x_inout. */
+int32_t qps_solve(qps_handle h, double *x_inout, const qps_params *params, qps_info *info);
+
+/* Final z and y of the last qps_solve (length m each; either pointer may be NULL). Additive. */
+int32_t qps_get_dual(qps_handle h, double *z_out, double *y_out);
+
+/* The reference plugin pair, literally (host vectors in, device solve, host vectors out):
+ *   qps_linsys_init  == LinSysSolInit(vX, mP, vQ, mA, rho, 1/rho, sigma, n, m)       LinearSystemSolvers.jl:110-122
+ *   qps_linsys_solve == LinSysSol!(tuSolver, vXX, vZZ, vX, ..., vZ, vY, rho, 1/rho, sigma, n, m, changedRho)  :125-142
+ * Post-condition as in the reference: xx_out == x-tilde (n), zz_out == z-tilde (m). */
+int32_t qps_linsys_init(qps_handle h, double rho, double sigma, int32_t linsys, int32_t trsvBlock);
+int32_t qps_linsys_solve(qps_handle h, const double *x, const double *z, const double *y, double rho, double sigma,
+                         int32_t changed_rho, double *xx_out, double *zz_out);
+
+/* Batch of `count` independent dense QPs of identical shape (BASELINE config 4).  Problem b uses
+ * P + b*ldp*n ... i.e. arrays are stacked along a leading batch axis: P[count][n*n], A[count][m*n] (column-major
+ * each), q[count][n], l/u[count][m].  x_inout is [count][n]; infos (may be NULL) is [count]. */
+int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, const double *P, const double *A, const double *q,
+                               const double *l, const double *u, int32_t dtype, int32_t device, qps_handle *out);
+int32_t qps_solve_batch(qps_handle h, double *x_inout, const qps_params *params, qps_info *infos);
+
+/* Device-time of the dominant loop kernels of the last qps_solve, measured with HIP events on the solver's stream
+ * (used by bench.py's roofline block).  names is a caller buffer of `cap` entries; returns the number filled. */
+typedef struct { char name[48]; double seconds; int64_t launches; double algo_bytes; } qps_kernel_time;
+int32_t qps_kernel_times(qps_handle h, qps_kernel_time *out, int32_t cap, int32_t *count);
+/* 1 = bracket every loop kernel with HIP events (slows the loop; off by default). */
+int32_t qps_set_profiling(qps_handle h, int32_t on);
+
+int32_t qps_destroy(qps_handle h);
+/* Human-readable description of the last failure on this handle (or of the last failed create when h == NULL). */
+const char *qps_last_error(qps_handle h);
+const char *qps_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPS_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of libqps_hip.so (C ABI declared in include/qps.h).
+
+The library is the product: there is no Python/CPU fallback.  If the shared object is missing or no MI355X is
+visible, every call fails loudly (``QpsLibraryError`` / ``QpsError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libqps_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+# every symbol include/qps.h declares (tests check that the library exports exactly these)
+EXPORTED_SYMBOLS = [
+    "qps_default_params", "qps_device_count", "qps_create_dense", "qps_create_csc", "qps_solve", "qps_get_dual",
+    "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
+    "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
+]
+
+QPS_OK = 0
+STATUS_NAMES = {0: "QPS_OK", 1: "QPS_ERR_BAD_ARGUMENT", 2: "QPS_ERR_BAD_DIMENSION", 3: "QPS_ERR_NOT_FINITE",
+                4: "QPS_ERR_FACTORIZATION", 5: "QPS_ERR_HIP", 6: "QPS_ERR_OUT_OF_MEMORY", 7: "QPS_ERR_NO_DEVICE",
+                8: "QPS_ERR_UNSUPPORTED"}
+QPS_F64, QPS_F32 = 0, 1
+QPS_LINSYS_AUTO, QPS_LINSYS_CHOLESKY, QPS_LINSYS_CG = 0, 1, 2
+
+
+class QpsLibraryError(RuntimeError):
+    """libqps_hip.so is missing / cannot be loaded."""
+
+
+class QpsError(RuntimeError):
+    """A libqps_hip call returned a non-zero qps_status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+class QpsParams(C.Structure):
+    _fields_ = [("numIterations", C.c_int32), ("adptRho", C.c_int32), ("numItrConv", C.c_int32),
+                ("numItrPolish", C.c_int32), ("numItrMinres", C.c_int32), ("linsys", C.c_int32),
+                ("trsvBlock", C.c_int32), ("reuseFactor", C.c_int32),
+                ("epsAbs", C.c_double), ("epsRel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
+                ("alpha", C.c_double), ("delta", C.c_double), ("fctrRho", C.c_double), ("epsMinres", C.c_double),
+                ("epsPcg", C.c_double), ("numItrPcg", C.c_int32), ("reserved", C.c_int32)]
+
+
+class QpsInfo(C.Structure):
+    _fields_ = [("convFlag", C.c_int32), ("iterations", C.c_int32), ("numRefactor", C.c_int32),
+                ("cgIterations", C.c_int32), ("rhoFinal", C.c_double), ("rhoProposed", C.c_double),
+                ("resPrim", C.c_double), ("resDual", C.c_double), ("tSetup", C.c_double), ("tLoop", C.c_double),
+                ("tRefactor", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class QpsKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("seconds", C.c_double), ("launches", C.c_int64), ("algo_bytes", C.c_double)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        sys.stderr.write(res.stdout)
+    if res.returncode != 0:
+        raise QpsLibraryError("building libqps_hip.so failed (see compiler output above)")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QpsLibraryError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise QpsLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    i32, i64, dbl, hp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
+    L.qps_default_params.argtypes = [C.POINTER(QpsParams)]
+    L.qps_device_count.argtypes = []
+    L.qps_create_dense.argtypes = [i64, i64, dp, i64, dp, i64, dp, dp, dp, i32, i32, C.POINTER(hp)]
+    L.qps_create_csc.argtypes = [i64, i64, ip, ip, dp, ip, ip, dp, dp, dp, dp, i32, i32, i32, i32, C.POINTER(hp)]
+    L.qps_solve.argtypes = [hp, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo)]
+    L.qps_get_dual.argtypes = [hp, dp, dp]
+    L.qps_linsys_init.argtypes = [hp, dbl, dbl, i32, i32]
+    L.qps_linsys_solve.argtypes = [hp, dp, dp, dp, dbl, dbl, i32, dp, dp]
+    L.qps_create_dense_batch.argtypes = [i64, i64, i64, dp, dp, dp, dp, dp, i32, i32, C.POINTER(hp)]
+    L.qps_solve_batch.argtypes = [hp, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo)]
+    L.qps_kernel_times.argtypes = [hp, C.POINTER(QpsKernelTime), i32, C.POINTER(i32)]
+    L.qps_set_profiling.argtypes = [hp, i32]
+    L.qps_destroy.argtypes = [hp]
+    L.qps_last_error.argtypes = [hp]
+    L.qps_last_error.restype = C.c_char_p
+    L.qps_version.argtypes = []
+    L.qps_version.restype = C.c_char_p
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("qps_last_error", "qps_version"):
+            getattr(L, name).restype = C.c_int32
+    _lib = L
+    return L
+
+
+def check(status: int, handle=None):
+    if status != QPS_OK:
+        msg = lib().qps_last_error(handle if handle else None)
+        raise QpsError(status, (msg or b"").decode("utf-8", "replace"))
+
+
+def default_params() -> QpsParams:
+    p = QpsParams()
+    check(lib().qps_default_params(C.byref(p)))
+    return p

@@ -1,0 +1,316 @@
+// k_loop.hip -- per-iteration kernels of the device-resident ADMM loop (gfx950 / CDNA4, wave64).
+// All of them are HBM-bound (<= 0.25 flop/byte): 16-byte-per-lane coalesced loads, wave64 shuffle reductions, no MFMA.
+#include "qps_kernels.h"
+
+namespace qps {
+
+namespace {
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// NaN-propagating max of non-negative values via their bit pattern (IEEE: for x >= 0 the unsigned order of the bits
+// is the numeric order, and a positive NaN sorts above +Inf), matching Julia's norm(v, Inf) / max.
+__device__ __forceinline__ unsigned long long absbits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-dot GEMV: one workgroup (256 threads) owns RB rows and walks their columns in chunks of 256 lanes x 16 B.
+// Used for: z~ = A x~ (LinearSystemSolvers.jl:139), both triangular sweeps over S, P x / A x in CheckConvergence.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int RB, int TRI>
+__global__ __launch_bounds__(256) void k_gemv_rows(const T* __restrict__ S, int64_t ld, const T* __restrict__ v,
+                                                   T* __restrict__ out, const T* __restrict__ out0, T alpha, T beta,
+                                                   int r0, int c0, int c1) {
+    using V = typename VecOf<T>::type;
+    constexpr int VN = VecOf<T>::N;
+    constexpr int CHUNK = 256 * VN;
+    const int tid = threadIdx.x;
+    const int rb = r0 + blockIdx.x * RB;
+    int cb = c0, ce = c1;
+    if (TRI == 1) ce = min(c1, rb + RB);
+    if (TRI == 2) cb = max(c0, rb);
+    T acc[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) acc[i] = T(0);
+    const T* Srow = S + (int64_t)rb * ld;
+#pragma unroll 2
+    for (int c = cb + tid * VN; c < ce; c += CHUNK) {
+        const V vv = *reinterpret_cast<const V*>(v + c);
+        const T* vp = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const V a = *reinterpret_cast<const V*>(Srow + (int64_t)i * ld + c);
+            const T* ap = reinterpret_cast<const T*>(&a);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                bool ok = true;
+                if (TRI == 1) ok = (c + e) <= (rb + i);
+                if (TRI == 2) ok = (c + e) >= (rb + i);
+                acc[i] += ok ? ap[e] * vp[e] : T(0);
+            }
+        }
+    }
+    __shared__ T red[4][RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) acc[i] = wave_sum(acc[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) red[tid >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < RB) {
+        T s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        T r = alpha * s;
+        if (beta != T(0)) r += beta * out0[rb + tid];
+        out[rb + tid] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column-accumulate GEMV (A'w): lanes own columns (16 B each), a workgroup owns RT rows x (256*VN) columns and
+// writes its partial sums to a slab; colsum() adds the slabs in a fixed order (deterministic, no float atomics).
+// w is formed on the fly: w[r] = ca*va[r] + cb*vb[r]   (LinearSystemSolvers.jl:134  rho*z - y).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GC_RT = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemv_cols(const T* __restrict__ S, int64_t ld, const T* __restrict__ va,
+                                                   const T* __restrict__ vb, T ca, T cb, T* __restrict__ part,
+                                                   int64_t part_ld, int ncols) {
+    using V = typename VecOf<T>::type;
+    constexpr int VN = VecOf<T>::N;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * VN;
+    if (c >= ncols) return;
+    const int rt = blockIdx.y;
+    const int rbase = rt * GC_RT;
+    T acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = T(0);
+    const T* Sp = S + (int64_t)rbase * ld + c;
+#pragma unroll 8
+    for (int i = 0; i < GC_RT; ++i) {
+        T w = ca * va[rbase + i];
+        if (vb) w += cb * vb[rbase + i];
+        const V a = *reinterpret_cast<const V*>(Sp + (int64_t)i * ld);
+        const T* ap = reinterpret_cast<const T*>(&a);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] += ap[e] * w;
+    }
+    V o;
+    T* op = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) op[e] = acc[e];
+    *reinterpret_cast<V*>(part + (int64_t)rt * part_ld + c) = o;
+}
+
+// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  Workgroup = 16 columns x 16 tile lanes: each 128-B line of a
+// slab row is read by 16 lanes, 16 slab rows per workgroup-iteration.
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int64_t part_ld, int ntiles,
+                                                const T* __restrict__ a0, T s0, const T* __restrict__ a1, T s1,
+                                                T* __restrict__ out, int ncols) {
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    T acc = T(0);
+    if (c < ncols)
+        for (int t = tl; t < ntiles; t += 16) acc += part[(int64_t)t * part_ld + c];
+    __shared__ T red[16][17];
+    red[tl][cl] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < ncols) {
+        T s = T(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += red[t][threadIdx.x];   // fixed order -> bitwise reproducible
+        T r = s;
+        if (a0) r += s0 * a0[c];
+        if (a1) r += s1 * a1[c];
+        out[c] = r;
+    }
+}
+
+// SolveQuadraticProgram.jl:56-61
+template <typename T>
+__global__ __launch_bounds__(256) void k_admm_update(int NP, int MP, const T* __restrict__ xx, const T* __restrict__ zz,
+                                                     T* __restrict__ x, T* __restrict__ xp, T* __restrict__ z,
+                                                     T* __restrict__ zp, T* __restrict__ y, const T* __restrict__ l,
+                                                     const T* __restrict__ u, T alpha, T rho) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const T alpha1 = T(1) - alpha, rho1 = T(1) / rho;
+    if (i < NP) {
+        const T xo = x[i];
+        xp[i] = xo;                                   // :56 copyto!(vXP, vX)
+        x[i] = alpha * xx[i] + alpha1 * xo;           // :57
+    }
+    if (i < MP) {
+        const T zo = z[i], yo = y[i], zt = zz[i];
+        zp[i] = zo;                                   // :59
+        T t = alpha * zt + alpha1 * zo + rho1 * yo;   // :60 clamp(x, lo, hi) = x > hi ? hi : (x < lo ? lo : x)
+        const T lo = l[i], hi = u[i];
+        const T zn = t > hi ? hi : (t < lo ? lo : t);
+        z[i] = zn;
+        y[i] = yo + rho * (alpha * zt + alpha1 * zo - zn);   // :61 (old z == vZP, new z)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CheckConvergence (SolveQuadraticProgram.jl:79-112).  Stage 1: nine inf-norms by wave64 shuffle + u64 atomicMax.
+// slots: 0 ||Ax-z|| 1 ||Px+q+A'y|| 2 ||Ax|| 3 ||z|| 4 ||Px|| 5 ||A'y|| 6 ||q|| 7 ||x-xp|| 8 ||z-zp||
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_check_norms(int n, int m, const T* __restrict__ Ax, const T* __restrict__ Px,
+                                                     const T* __restrict__ Aty, const T* __restrict__ q,
+                                                     const T* __restrict__ x, const T* __restrict__ xp,
+                                                     const T* __restrict__ z, const T* __restrict__ zp,
+                                                     unsigned long long* __restrict__ slots) {
+    unsigned long long v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = 0ull;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < max(n, m); i += gridDim.x * 256) {
+        if (i < m) {
+            const double ax = (double)Ax[i], zi = (double)z[i];
+            // differences are formed in T to match a T-precision reference of norm(mA * vX - vZ, Inf)
+            v[0] = max(v[0], absbits((double)(Ax[i] - z[i])));
+            v[2] = max(v[2], absbits(ax));
+            v[3] = max(v[3], absbits(zi));
+            v[8] = max(v[8], absbits((double)(z[i] - zp[i])));
+        }
+        if (i < n) {
+            v[1] = max(v[1], absbits((double)(Px[i] + q[i] + Aty[i])));
+            v[4] = max(v[4], absbits((double)Px[i]));
+            v[5] = max(v[5], absbits((double)Aty[i]));
+            v[6] = max(v[6], absbits((double)q[i]));
+            v[7] = max(v[7], absbits((double)(x[i] - xp[i])));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        v[k] = wave_max_u64(v[k]);
+        if ((threadIdx.x & 63) == 0 && v[k] != 0ull) atomicMax(&slots[k], v[k]);
+    }
+}
+
+__device__ __forceinline__ double jmax(double a, double b) { return (isnan(a) || isnan(b)) ? (double)NAN : (a > b ? a : b); }
+
+// Stage 2 (one thread): rho proposal + the two termination tests, in fp64 on the reduced scalars.
+__global__ void k_check_decide(const unsigned long long* __restrict__ slots, double* __restrict__ res, CheckScalars cs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double nv[9];
+    for (int k = 0; k < 9; ++k) nv[k] = __longlong_as_double((long long)slots[k]);
+    const double MIN_VAL_RHO = 1e-3, MAX_VAL_RHO = 1e6;          // :81-82
+    const double normResPrim = nv[0], normResDual = nv[1];        // :85-86
+    const double maxNormPrim = jmax(nv[2], nv[3]);                // :88
+    const double maxNormDual = jmax(jmax(nv[4], nv[5]), nv[6]);   // :89
+    double rhorho = cs.rhorho;
+    if (cs.adptRho) {                                             // :92-96
+        const double numeratorVal = normResPrim * maxNormDual;
+        const double denominatorVal = normResDual * maxNormPrim;
+        const double t = cs.rho * sqrt(numeratorVal / denominatorVal);
+        rhorho = t > MAX_VAL_RHO ? MAX_VAL_RHO : (t < MIN_VAL_RHO ? MIN_VAL_RHO : t);
+    }
+    const double epsPrim = cs.epsAbs + cs.epsRel * maxNormPrim;   // :99
+    const double epsDual = cs.epsAbs + cs.epsRel * maxNormDual;   // :100
+    int flag = cs.convFlag;
+    if ((normResPrim < epsPrim) && (normResDual < epsDual)) flag = 3;     // :102-104 convPrimDual
+    if ((nv[7] <= cs.epsAdmm) && (nv[8] <= cs.epsAdmm)) flag = 2;          // :105-107 convAdmm (not else)
+    res[0] = normResPrim; res[1] = normResDual; res[2] = maxNormPrim; res[3] = maxNormDual;
+    res[4] = rhorho; res[5] = (double)flag; res[6] = nv[7]; res[7] = nv[8];
+}
+
+template <typename T> __global__ void k_fill(T* p, int64_t n, T v) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+template <typename T> __global__ void k_convert(const double* __restrict__ s, T* __restrict__ d, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d[i] = (T)s[i];
+}
+template <typename T> __global__ void k_convert_back(const T* __restrict__ s, double* __restrict__ d, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d[i] = (double)s[i];
+}
+
+}  // namespace
+
+template <typename T>
+void gemv_rows(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta, int r0, int r1,
+               int c0, int c1, int tri) {
+    constexpr int RB = 4;
+    if (r1 <= r0) return;
+    dim3 grid((r1 - r0 + RB - 1) / RB), block(256);
+    if (tri == 0) hipLaunchKernelGGL((k_gemv_rows<T, RB, 0>), grid, block, 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1);
+    else if (tri == 1) hipLaunchKernelGGL((k_gemv_rows<T, RB, 1>), grid, block, 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1);
+    else hipLaunchKernelGGL((k_gemv_rows<T, RB, 2>), grid, block, 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1);
+}
+
+int gemv_cols_tiles(int nrows) { return (nrows + GC_RT - 1) / GC_RT; }
+
+template <typename T>
+int gemv_cols_partial(hipStream_t st, const T* S, int64_t ld, const T* va, const T* vb, T ca, T cb, T* part,
+                      int64_t part_ld, int nrows, int ncols) {
+    constexpr int VN = VecOf<T>::N;
+    const int tiles = gemv_cols_tiles(nrows);
+    if (tiles == 0) return 0;
+    dim3 grid((ncols + 256 * VN - 1) / (256 * VN), tiles), block(256);
+    hipLaunchKernelGGL((k_gemv_cols<T>), grid, block, 0, st, S, ld, va, vb, ca, cb, part, part_ld, ncols);
+    return tiles;
+}
+
+template <typename T>
+void colsum(hipStream_t st, const T* part, int64_t part_ld, int ntiles, const T* a0, T s0, const T* a1, T s1, T* out,
+            int ncols) {
+    hipLaunchKernelGGL((k_colsum<T>), dim3((ncols + 15) / 16), dim3(256), 0, st, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols);
+}
+
+template <typename T>
+void admm_update(hipStream_t st, int NP, int MP, const T* xx, const T* zz, T* x, T* xp, T* z, T* zp, T* y, const T* l,
+                 const T* u, T alpha, T rho) {
+    const int N = NP > MP ? NP : MP;
+    hipLaunchKernelGGL((k_admm_update<T>), dim3((N + 255) / 256), dim3(256), 0, st, NP, MP, xx, zz, x, xp, z, zp, y, l, u, alpha, rho);
+}
+
+template <typename T>
+void check_convergence(hipStream_t st, int n, int m, const T* Ax, const T* Px, const T* Aty, const T* q, const T* x,
+                       const T* xp, const T* z, const T* zp, unsigned long long* scratch, double* res_dev, CheckScalars cs) {
+    (void)hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long), st);
+    const int N = n > m ? n : m;
+    int blocks = (N + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_check_norms<T>), dim3(blocks), dim3(256), 0, st, n, m, Ax, Px, Aty, q, x, xp, z, zp, scratch);
+    hipLaunchKernelGGL(k_check_decide, dim3(1), dim3(64), 0, st, scratch, res_dev, cs);
+}
+
+template <typename T> void fill(hipStream_t st, T* p, int64_t n, T v) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((k_fill<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+template <typename T> void convert_copy(hipStream_t st, const double* src, T* dst, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((k_convert<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+template <typename T> void convert_back(hipStream_t st, const T* src, double* dst, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((k_convert_back<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
+#define INST(T)                                                                                                              \
+    template void gemv_rows<T>(hipStream_t, const T*, int64_t, const T*, T*, const T*, T, T, int, int, int, int, int);       \
+    template int gemv_cols_partial<T>(hipStream_t, const T*, int64_t, const T*, const T*, T, T, T*, int64_t, int, int);      \
+    template void colsum<T>(hipStream_t, const T*, int64_t, int, const T*, T, const T*, T, T*, int);                         \
+    template void admm_update<T>(hipStream_t, int, int, const T*, const T*, T*, T*, T*, T*, T*, const T*, const T*, T, T);   \
+    template void check_convergence<T>(hipStream_t, int, int, const T*, const T*, const T*, const T*, const T*, const T*,    \
+                                       const T*, const T*, unsigned long long*, double*, CheckScalars);                      \
+    template void fill<T>(hipStream_t, T*, int64_t, T);                                                                      \
+    template void convert_copy<T>(hipStream_t, const double*, T*, int64_t);                                                  \
+    template void convert_back<T>(hipStream_t, const T*, double*, int64_t);
+INST(double)
+INST(float)
+#undef INST
+
+}  // namespace qps

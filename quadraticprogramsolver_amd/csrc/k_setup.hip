@@ -1,0 +1,271 @@
+// k_setup.hip -- one-off / per-refactor kernels: layout import, A'A (SYRK) and the blocked Cholesky on the fp64 / fp32
+// MFMA pipe (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32), inversion of the diagonal sweep blocks.
+// Reference: LinearSystemSolvers.jl:112-114 (mAA, mPI, mL), :127-129 (rebuild on changedRho), ProxQP.jl:175-206
+// (dense Cholesky + in-place re-factorisation precedent).
+#include "qps_kernels.h"
+
+namespace qps {
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+    using acc_t = d4;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma<float> {
+    using acc_t = f4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+
+constexpr int GT = 64;    // C tile edge per workgroup
+constexpr int GK = 16;    // K depth per LDS stage
+constexpr int GLD = 80;   // LDS row stride (elements): k-groups of a fragment read land 32 banks apart
+
+// 64 x 64 C tile per 256-thread workgroup; waves in a 2 x 2 grid, each wave 2 x 2 MFMA 16 x 16 tiles.
+template <typename T, bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                              int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
+                                              int64_t sA, int64_t sB, int64_t sC) {
+    const int bj = blockIdx.x, bi = blockIdx.y;
+    if (lower_only && bj > bi) return;
+    A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
+    __shared__ T As[GK][GLD];
+    __shared__ T Bs[GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    using acc_t = typename Mfma<T>::acc_t;
+    acc_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
+    const int i0 = bi * GT, j0 = bj * GT;
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        // stage opA(i0.., k0..) as As[k][i] and opB(k0.., j0..) as Bs[k][j]; 4 elements per thread each
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[k][i] = A[(int64_t)(i0 + i) * lda + k0 + k]; }
+            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[k][i] = A[(int64_t)(k0 + k) * lda + i0 + i]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[k][j] = B[(int64_t)(j0 + j) * ldb + k0 + k]; }
+            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[k][j] = B[(int64_t)(k0 + k) * ldb + j0 + j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            const int kr = kk + (lane >> 4), cl = lane & 15;
+            const T a0 = As[kr][wm * 32 + cl], a1 = As[kr][wm * 32 + 16 + cl];
+            const T b0 = Bs[kr][wn * 32 + cl], b1 = Bs[kr][wn * 32 + 16 + cl];
+            acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
+            acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
+            acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
+            acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm * 32 + a * 16 + Mfma<T>::row(lane, r);
+                const int col = j0 + wn * 32 + b * 16 + (lane & 15);
+                T* cp = C + (int64_t)row * ldc + col;
+                T v = alpha * acc[a][b][r];
+                if (beta != T(0)) v += beta * (*cp);
+                *cp = v;
+            }
+}
+
+// column-major double src (rows x cols) -> row-major T dst (ld ldd), via a 64 x 64 LDS transpose tile; dst padding is
+// left untouched (the caller zero-fills the allocation first).
+template <typename T>
+__global__ __launch_bounds__(256) void k_import_colmajor(const double* __restrict__ src, int64_t lds, int rows, int cols,
+                                                         T* __restrict__ dst, int64_t ldd) {
+    __shared__ T tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 64; cc += 4) {   // lanes along rows: contiguous in column-major src
+        const int r = r0 + tx, c = c0 + cc;
+        tile[cc][tx] = (r < rows && c < cols) ? (T)src[(int64_t)c * lds + r] : T(0);
+    }
+    __syncthreads();
+    for (int rr = ty; rr < 64; rr += 4) {   // lanes along columns: contiguous in row-major dst
+        const int r = r0 + rr, c = c0 + tx;
+        if (r < rows && c < cols) dst[(int64_t)r * ldd + c] = tile[tx][rr];
+    }
+}
+
+template <typename T>
+__global__ void k_make_PI(int n, int NP, const T* __restrict__ P, T sigma, T* __restrict__ PI) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= NP) return;
+    T v = T(0);
+    if (i < n && j < n) v = P[(int64_t)i * NP + j] + (i == j ? sigma : T(0));   // LinearSystemSolvers.jl:113
+    else if (i == j) v = T(1);
+    PI[(int64_t)i * NP + j] = v;
+}
+template <typename T>
+__global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restrict__ AA, T rho, T* __restrict__ M) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= NP || j > (i | 63)) return;                                          // lower tiles incl. whole diagonal tile
+    const int64_t o = (int64_t)i * NP + j;
+    // AA holds the lower tiles of A'A; inside a diagonal tile both halves are present
+    M[o] = PI[o] + rho * AA[o];                                                   // LinearSystemSolvers.jl:114 / :128
+}
+
+// Cholesky of one 64 x 64 diagonal block + its inverse.  256 threads: thread (i = tid & 63, g = tid >> 6).
+template <typename T>
+__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, T* __restrict__ dinv, int* __restrict__ fail) {
+    __shared__ T L[64][65];
+    __shared__ T X[64][65];
+    const int tid = threadIdx.x, i = tid & 63, g = tid >> 6;
+    T* blk = M + (int64_t)kb * 64 * ld + kb * 64;
+    for (int r = g; r < 64; r += 4) L[r][i] = blk[(int64_t)r * ld + i];
+    __syncthreads();
+    for (int k = 0; k < 64; ++k) {
+        T d = L[k][k];
+        if (!(d > T(0))) { if (tid == 0) atomicCAS(fail, 0, kb * 64 + k + 1); d = T(1); }
+        d = sqrt(d);
+        __syncthreads();
+        if (g == 0) { if (i == k) L[k][k] = d; else if (i > k) L[i][k] = L[i][k] / d; }
+        __syncthreads();
+        // trailing update of the lower triangle: L[i][j] -= L[i][k] * L[j][k], k < j <= i
+        const T lik = L[i][k];
+        if (i > k)
+            for (int j = k + 1 + g; j <= i; j += 4) L[i][j] -= lik * L[j][k];
+        __syncthreads();
+    }
+    // inverse by forward substitution, one column per thread (threads 0..63)
+    if (g == 0) {
+        const int j = i;
+        for (int r = 0; r < 64; ++r) {
+            T s = (r == j) ? T(1) : T(0);
+            if (r >= j) {
+                for (int k = j; k < r; ++k) s -= L[r][k] * X[k][j];
+                X[r][j] = s / L[r][r];
+            } else X[r][j] = T(0);
+        }
+    }
+    __syncthreads();
+    for (int r = g; r < 64; r += 4) {
+        blk[(int64_t)r * ld + i] = (i <= r) ? L[r][i] : T(0);
+        dinv[(int64_t)kb * 4096 + r * 64 + i] = X[r][i];
+    }
+}
+
+// S lower <- L lower with the 64-blocks on the diagonal replaced by their inverses; S upper <- 0
+template <typename T>
+__global__ void k_init_sweep(int NP, const T* __restrict__ L, const T* __restrict__ dinv, T* __restrict__ S) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= NP) return;
+    T v = T(0);
+    if ((i >> 6) == (j >> 6)) v = dinv[(int64_t)(i >> 6) * 4096 + (i & 63) * 64 + (j & 63)];
+    else if (j < i) v = L[(int64_t)i * NP + j];
+    S[(int64_t)i * NP + j] = v;
+}
+// S[j][i] = S[i][j] for j < i, 64 x 64 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void k_mirror(int NP, T* __restrict__ S) {
+    const int bj = blockIdx.x, bi = blockIdx.y;
+    if (bj > bi) return;
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = S[(int64_t)(bi * 64 + r) * NP + bj * 64 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        // destination element (row = bj*64 + r, col = bi*64 + tx) = source (bi*64 + tx, bj*64 + r)
+        if (bi != bj || tx > r) S[(int64_t)(bj * 64 + r) * NP + bi * 64 + tx] = tile[tx][r];
+    }
+}
+
+}  // namespace
+
+template <typename T>
+void import_colmajor(hipStream_t st, const double* src, int64_t lds, int rows, int cols, T* dst, int64_t ldd) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL((k_import_colmajor<T>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, lds, rows, cols, dst, ldd);
+}
+
+template <typename T>
+void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda, bool ak, const T* B, int64_t ldb, bool bk,
+          T beta, T* C, int64_t ldc, bool lower_only, int batch, int64_t sA, int64_t sB, int64_t sC) {
+    if (M <= 0 || N <= 0 || batch <= 0) return;
+    dim3 grid(N / GT, M / GT, batch), block(256);
+    const int lo = lower_only ? 1 : 0;
+    if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
+    else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
+    else if (!ak && bk) hipLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
+    else hipLaunchKernelGGL((k_gemm<T, false, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
+}
+
+template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI) {
+    hipLaunchKernelGGL((k_make_PI<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, n, NP, P, sigma, PI);
+}
+template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M) {
+    hipLaunchKernelGGL((k_assemble_M<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, NP, PI, AA, rho, M);
+}
+
+template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev) {
+    (void)hipMemsetAsync(fail_dev, 0, sizeof(int), st);
+    const int nblk = NP / 64;
+    for (int kb = 0; kb < nblk; ++kb) {
+        hipLaunchKernelGGL((k_potrf64<T>), dim3(1), dim3(256), 0, st, M, (int64_t)NP, kb, dinv, fail_dev);
+        const int rem = NP - (kb + 1) * 64;
+        if (rem <= 0) break;
+        T* A21 = M + (int64_t)(kb + 1) * 64 * NP + kb * 64;
+        // L21 = A21 * inv(L11)'   (in place: each workgroup reads exactly the 64 x 64 block it overwrites)
+        gemm<T>(st, rem, 64, 64, T(1), A21, NP, true, dinv + (int64_t)kb * 4096, 64, true, T(0), A21, NP, false);
+        // A22 -= L21 * L21'  (lower tiles only)
+        T* A22 = M + (int64_t)(kb + 1) * 64 * NP + (kb + 1) * 64;
+        gemm<T>(st, rem, rem, 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true);
+    }
+}
+
+template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp) {
+    hipLaunchKernelGGL((k_init_sweep<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, NP, L, dinv, S);
+    // recursive doubling: inv([L00 0; L10 L11]) = [inv00 0; -inv11 L10 inv00, inv11]
+    for (int s = 64; s < nb; s *= 2) {
+        const int64_t pstride = (int64_t)2 * s * (NP + 1);
+        int nfull = 0;
+        while ((nfull + 1) * 2 * s <= NP) ++nfull;
+        if (nfull > 0) {
+            // tmp10 = L10 * inv00 ; S10 = -inv11 * tmp10     (batched over the pairs)
+            gemm<T>(st, s, s, s, T(1), L + (int64_t)s * NP, NP, true, S, NP, false, T(0), tmp + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride);
+            gemm<T>(st, s, s, s, T(-1), S + (int64_t)s * (NP + 1), NP, true, tmp + (int64_t)s * NP, NP, false, T(0), S + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride);
+        }
+        const int o = nfull * 2 * s;
+        const int s2 = NP - o - s;
+        if (s2 > 0) {   // ragged last pair: second block has s2 < s rows
+            const T* L10 = L + (int64_t)(o + s) * NP + o;
+            T* t10 = tmp + (int64_t)(o + s) * NP + o;
+            gemm<T>(st, s2, s, s, T(1), L10, NP, true, S + (int64_t)o * (NP + 1), NP, false, T(0), t10, NP, false);
+            gemm<T>(st, s2, s, s2, T(-1), S + (int64_t)(o + s) * (NP + 1), NP, true, t10, NP, false, T(0), S + (int64_t)(o + s) * NP + o, NP, false);
+        }
+    }
+    hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64), dim3(256), 0, st, NP, S);
+}
+
+#define INST(T)                                                                                                        \
+    template void import_colmajor<T>(hipStream_t, const double*, int64_t, int, int, T*, int64_t);                      \
+    template void gemm<T>(hipStream_t, int, int, int, T, const T*, int64_t, bool, const T*, int64_t, bool, T, T*, int64_t, \
+                          bool, int, int64_t, int64_t, int64_t);                                                       \
+    template void make_PI<T>(hipStream_t, int, int, const T*, T, T*);                                                  \
+    template void assemble_M<T>(hipStream_t, int, const T*, const T*, T, T*);                                          \
+    template void cholesky<T>(hipStream_t, int, T*, T*, int*);                                                         \
+    template void build_sweep_matrix<T>(hipStream_t, int, int, const T*, const T*, T*, T*);
+INST(double)
+INST(float)
+#undef INST
+
+}  // namespace qps

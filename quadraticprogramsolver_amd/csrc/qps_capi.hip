@@ -1,0 +1,500 @@
+// qps_capi.hip -- the C ABI of include/qps.h: handle table, problem import, the device-resident ADMM loop driver.
+//
+// Loop structure follows SolveQuadraticProgram.jl:36-73; the linear solve is the reduced form of
+// LinearSystemSolvers.jl:110-142 with cg! replaced by Cholesky + two triangular sweeps (ProxQP.jl:175-206,221-225).
+// There is NO CPU fallback: without a HIP device every entry point fails with QPS_ERR_NO_DEVICE.
+#include "qps_internal.h"
+#include "qps_kernels.h"
+
+using namespace qps;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int pick_nb(int requested, int NP) {
+    int nb = requested > 0 ? requested : 2048;
+    int p = 64; while (p * 2 <= nb) p *= 2;   // power-of-two multiple of 64
+    nb = p;
+    while (nb > 64 && nb / 2 >= NP) nb /= 2;
+    return nb;
+}
+
+// =================================================================================================================
+// Dense problem, Cholesky path
+// =================================================================================================================
+template <typename T> struct DenseSolver : SolverBase {
+    int NP = 0, MP = 0;
+    T *A = nullptr, *P = nullptr, *q = nullptr, *l = nullptr, *u = nullptr;
+    T *PI = nullptr, *AA = nullptr, *M = nullptr, *S = nullptr, *tmp = nullptr, *dinv = nullptr; int* fail = nullptr;
+    T *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr, *xx = nullptr, *zz = nullptr, *tt = nullptr, *yv = nullptr;
+    T *part = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
+    unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
+    bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
+    int nb = 2048; int part_tiles = 0;
+    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk;
+
+    DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
+        device = dev; n = n_; m = m_; dtype = dt;
+        HIPC(hipSetDevice(device));
+        HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        prof.st = st;
+        NP = roundup(n, 64); MP = roundup(m, 64);
+        const int64_t nn = (int64_t)NP * NP;
+        A = dalloc<T>((int64_t)MP * NP); P = dalloc<T>(nn); q = dalloc<T>(NP); l = dalloc<T>(MP); u = dalloc<T>(MP);
+        PI = dalloc<T>(nn); AA = dalloc<T>(nn); M = dalloc<T>(nn); S = dalloc<T>(nn); tmp = dalloc<T>(nn);
+        dinv = dalloc<T>((int64_t)(NP / 64) * 4096); fail = dalloc<int>(4);
+        x = dalloc<T>(NP); xp = dalloc<T>(NP); xx = dalloc<T>(NP); tt = dalloc<T>(NP); yv = dalloc<T>(NP);
+        z = dalloc<T>(MP); zp = dalloc<T>(MP); y = dalloc<T>(MP); zz = dalloc<T>(MP);
+        part_tiles = gemv_cols_tiles(MP);
+        part = dalloc<T>((int64_t)(part_tiles > 0 ? part_tiles : 1) * NP);
+        Ax = dalloc<T>(MP); Px = dalloc<T>(NP); Aty = dalloc<T>(NP);
+        scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
+        HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
+        stage = dalloc<double>((int64_t)NP + 2 * (int64_t)MP + 64);
+        const double s = sizeof(T);
+        // algorithmic bytes per launch (SURVEY §8d "per-kernel algorithmic bytes")
+        cat_atw = prof.category("gemv_cols(A'w)", s * ((double)m * n + m + n));
+        cat_colsum = prof.category("colsum(rhs)", s * ((double)part_tiles * n + 3.0 * n));
+        cat_fwd = prof.category("trsv_forward", s * ((double)n * (n + 1) / 2 + 2.0 * n));
+        cat_bwd = prof.category("trsv_backward", s * ((double)n * (n + 1) / 2 + 2.0 * n));
+        cat_ax = prof.category("gemv_rows(Ax~)", s * ((double)m * n + m + n));
+        cat_upd = prof.category("admm_update", s * (3.0 * n + 7.0 * m));
+        cat_chk = prof.category("check_convergence", s * (2.0 * m * n + (double)n * n + 4.0 * n + 4.0 * m));
+    }
+    ~DenseSolver() override {
+        (void)hipSetDevice(device);
+        if (st) (void)hipStreamSynchronize(st);
+        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, Ax, Px, Aty, scratch, res_dev, stage};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (res_host) (void)hipHostFree(res_host);
+        if (st) (void)hipStreamDestroy(st);
+    }
+
+    // host double array -> device T vector (zero padded allocation is preserved beyond `count`)
+    void upload_vec(const double* h, T* d, int64_t count) {
+        if (count <= 0) return;
+        HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, st));
+        convert_copy<T>(st, stage, d, count);
+        HIPC(hipStreamSynchronize(st));
+    }
+    void download_vec(const T* d, double* h, int64_t count) {
+        if (count <= 0) return;
+        convert_back<T>(st, d, stage, count);
+        HIPC(hipMemcpyAsync(h, stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    // column-major host matrix -> row-major device T (streamed through a bounded staging buffer, column panels)
+    void upload_matrix(const double* h, int64_t ldh, int rows, int cols, T* d, int64_t ldd) {
+        if (rows <= 0 || cols <= 0) return;
+        const int64_t budget = (int64_t)32 << 20;   // doubles per panel (256 MiB)
+        int pc = (int)std::max<int64_t>(64, (budget / std::max(rows, 1)) / 64 * 64);
+        double* buf = nullptr;
+        HIPC(hipMalloc((void**)&buf, sizeof(double) * (size_t)rows * (size_t)std::min(pc, cols)));
+        for (int c0 = 0; c0 < cols; c0 += pc) {
+            const int nc = std::min(pc, cols - c0);
+            HIPC(hipMemcpy2DAsync(buf, sizeof(double) * (size_t)rows, h + (int64_t)c0 * ldh, sizeof(double) * (size_t)ldh,
+                                  sizeof(double) * (size_t)rows, (size_t)nc, hipMemcpyHostToDevice, st));
+            import_colmajor<T>(st, buf, rows, rows, nc, d + c0, ldd);
+            HIPC(hipStreamSynchronize(st));
+        }
+        HIPC(hipFree(buf));
+    }
+
+    // LinSysSolInit: LinearSystemSolvers.jl:110-122 (mAA, mPI, mL) + factorisation (ProxQP.jl:196)
+    void factorize(double rho, double sigma, bool rebuild_all) {
+        if (rebuild_all || !have_AA) {
+            make_PI<T>(st, (int)n, NP, P, (T)sigma, PI);                                             // :113
+            if (MP > 0) gemm<T>(st, NP, NP, MP, T(1), A, NP, false, A, NP, false, T(0), AA, NP, true); // :112 mAA = mA' mA
+            else HIPC(hipMemsetAsync(AA, 0, sizeof(T) * (size_t)NP * NP, st));
+            have_AA = true;
+        }
+        assemble_M<T>(st, NP, PI, AA, (T)rho, M);                                                    // :114 / :128
+        cholesky<T>(st, NP, M, dinv, fail);
+        build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp);
+        int f = 0;
+        HIPC(hipMemcpyAsync(&f, fail, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        if (f != 0) {
+            factor_valid = false;
+            char b[256]; snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A broke down: non-positive pivot at column %d (rho=%g, sigma=%g)", f, rho, sigma);
+            throw QpsError(QPS_ERR_FACTORIZATION, b);
+        }
+        factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb;
+    }
+
+    // x~ = (L L')^{-1} tt via the blocked sweeps over S (tt is consumed)
+    void sweeps() {
+        const int nblk = (NP + nb - 1) / nb;
+        {
+            ProfScope ps(prof, cat_fwd, 2);
+            for (int J = 0; J < nblk; ++J) {
+                const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
+                gemv_rows<T>(st, S, NP, tt, yv, nullptr, T(1), T(0), r0, r1, r0, r1, 1);
+                if (r1 < NP) gemv_rows<T>(st, S, NP, yv, tt, tt, T(-1), T(1), r1, NP, r0, r1, 0);
+            }
+        }
+        {
+            ProfScope ps(prof, cat_bwd, 2);
+            for (int J = nblk - 1; J >= 0; --J) {
+                const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
+                gemv_rows<T>(st, S, NP, yv, xx, nullptr, T(1), T(0), r0, r1, r0, r1, 2);
+                if (r0 > 0) gemv_rows<T>(st, S, NP, xx, yv, yv, T(-1), T(1), 0, r0, r0, r1, 0);
+            }
+        }
+    }
+    // LinSysSol! body: LinearSystemSolvers.jl:134-139
+    void linear_solve(double rho, double sigma) {
+        {
+            ProfScope ps(prof, cat_atw, 1);
+            gemv_cols_partial<T>(st, A, NP, z, y, (T)rho, T(-1), part, NP, MP, NP);                  // :134-135
+        }
+        {
+            ProfScope ps(prof, cat_colsum, 2);
+            colsum<T>(st, part, NP, part_tiles, x, (T)sigma, q, T(-1), tt, NP);                      // :136
+        }
+        sweeps();                                                                                   // :137 (Cholesky instead of cg!)
+        {
+            ProfScope ps(prof, cat_ax, 2);
+            gemv_rows<T>(st, A, NP, xx, zz, nullptr, T(1), T(0), 0, MP, 0, NP, 0);                   // :139
+        }
+    }
+
+    void solve(double* xh, const qps_params& p, qps_info* info) override {
+        HIPC(hipSetDevice(device));
+        const double t0 = now_s();
+        nb = pick_nb(p.trsvBlock, NP);
+        double rho = p.rho, sigma = p.sigma; const double alpha = p.alpha;
+        const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;                                // SolveQuadraticProgram.jl:34
+        int convFlag = QPS_CONV_NUM_ITR;                                                            // :33
+        const bool reuse = p.reuseFactor && factor_valid && fac_rho == rho && fac_sigma == sigma && fac_nb == nb;
+        if (!reuse) factorize(rho, sigma, !p.reuseFactor || !have_AA || fac_sigma != sigma);        // :36
+        upload_vec(xh, x, n);
+        HIPC(hipMemsetAsync(xp, 0, sizeof(T) * NP, st));                                            // :38
+        HIPC(hipMemsetAsync(z, 0, sizeof(T) * std::max(MP, 64), st));                               // :39
+        HIPC(hipMemsetAsync(y, 0, sizeof(T) * std::max(MP, 64), st));                               // :40
+        HIPC(hipMemsetAsync(zp, 0, sizeof(T) * std::max(MP, 64), st));                              // :41
+        HIPC(hipStreamSynchronize(st));
+        const double t1 = now_s();
+        double rhorho = rho;                                                                        // :43
+        int ii = 0, nref = 0; double tref = 0, resP = NAN, resD = NAN;
+        prof.reset();
+        for (ii = 1; ii <= p.numIterations; ++ii) {                                                 // :45
+            if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {          // :47
+                rho = rhorho; ++nref;                                                               // :48-51
+                const double ta = now_s();
+                factorize(rho, sigma, false);                                                       // changedΡ: LinearSystemSolvers.jl:127-129
+                tref += now_s() - ta;
+            }
+            linear_solve(rho, sigma);                                                               // :54
+            {
+                ProfScope ps(prof, cat_upd, 2);
+                admm_update<T>(st, NP, MP, xx, zz, x, xp, z, zp, y, l, u, (T)alpha, (T)rho);         // :56-61
+            }
+            if (ii % p.numItrConv == 0) {                                                           // :63
+                {
+                    ProfScope ps(prof, cat_chk, 2);
+                    gemv_rows<T>(st, A, NP, x, Ax, nullptr, T(1), T(0), 0, MP, 0, NP, 0);            // mA * vX
+                    gemv_rows<T>(st, P, NP, x, Px, nullptr, T(1), T(0), 0, NP, 0, NP, 0);            // mP * vX
+                    gemv_cols_partial<T>(st, A, NP, y, nullptr, T(1), T(0), part, NP, MP, NP);       // mA' * vY
+                    colsum<T>(st, part, NP, part_tiles, nullptr, T(0), nullptr, T(0), Aty, NP);
+                    CheckScalars cs{p.epsAbs, p.epsRel, epsAdmm, rho, rhorho, p.adptRho, convFlag};
+                    check_convergence<T>(st, (int)n, (int)m, Ax, Px, Aty, q, x, xp, z, zp, scratch, res_dev, cs);   // :64
+                }
+                HIPC(hipMemcpyAsync(res_host, res_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                prof.harvest();
+                resP = res_host[0]; resD = res_host[1]; rhorho = res_host[4]; convFlag = (int)res_host[5];
+                if (convFlag != QPS_CONV_NUM_ITR) break;                                            // :66-68
+            }
+        }
+        HIPC(hipStreamSynchronize(st));
+        prof.harvest();
+        const double t2 = now_s();
+        download_vec(x, xh, n);
+        if (info) {
+            info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
+            info->numRefactor = nref; info->cgIterations = 0; info->rhoFinal = rho; info->rhoProposed = rhorho;
+            info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = tref;
+        }
+    }
+    void get_dual(double* zh, double* yh) override {
+        HIPC(hipSetDevice(device));
+        if (zh) download_vec(z, zh, m);
+        if (yh) download_vec(y, yh, m);
+    }
+    void linsys_init(double rho, double sigma, int linsys, int nbreq) override {
+        HIPC(hipSetDevice(device));
+        if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "dense handles support QPS_LINSYS_CHOLESKY only");
+        nb = pick_nb(nbreq, NP);
+        factorize(rho, sigma, true);
+    }
+    void linsys_solve(const double* xh, const double* zh, const double* yh, double rho, double sigma, int changed,
+                      double* xxh, double* zzh) override {
+        HIPC(hipSetDevice(device));
+        if (!factor_valid && !changed) throw QpsError(QPS_ERR_BAD_ARGUMENT, "qps_linsys_solve called before qps_linsys_init");
+        if (changed) factorize(rho, sigma, false);                                                  // LinearSystemSolvers.jl:127-129
+        upload_vec(xh, x, n); upload_vec(zh, z, m); upload_vec(yh, y, m);
+        linear_solve(rho, sigma);
+        download_vec(xx, xxh, n); download_vec(zz, zzh, m);
+    }
+};
+
+// =================================================================================================================
+// handle plumbing
+// =================================================================================================================
+struct Handle { SolverBase* impl = nullptr; std::vector<SolverBase*> batch; int64_t n = 0, m = 0; std::string err; };
+
+int fail_with(Handle* h, int code, const std::string& msg) {
+    g_last_error = msg;
+    if (h) h->err = msg;
+    return code;
+}
+bool all_finite(const double* p, int64_t count, bool allow_inf) {
+    for (int64_t i = 0; i < count; ++i) {
+        const double v = p[i];
+        if (std::isnan(v)) return false;
+        if (!allow_inf && std::isinf(v)) return false;
+    }
+    return true;
+}
+int check_device(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return QPS_ERR_NO_DEVICE;
+    if (device < 0 || device >= cnt) return QPS_ERR_BAD_ARGUMENT;
+    return QPS_OK;
+}
+
+template <typename F> int guarded(Handle* h, F&& f) {
+    try { f(); return QPS_OK; }
+    catch (const QpsError& e) { return fail_with(h, e.code, e.msg); }
+    catch (const std::bad_alloc&) { return fail_with(h, QPS_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    catch (const std::exception& e) { return fail_with(h, QPS_ERR_HIP, e.what()); }
+}
+
+int validate_params(Handle* h, const qps_params* p) {
+    if (!p) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "params is NULL");
+    if (p->numIterations < 0) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "numIterations must be >= 0");
+    if (p->numItrConv <= 0) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "numItrConv must be positive");
+    if (!(p->rho > 0) || !std::isfinite(p->rho)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "rho must be positive and finite");
+    if (!(p->sigma >= 0) || !std::isfinite(p->sigma)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "sigma must be non-negative and finite");
+    if (!std::isfinite(p->alpha)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "alpha must be finite");
+    if (std::isnan(p->epsAbs) || std::isnan(p->epsRel)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "epsAbs/epsRel must not be NaN");
+    if (p->adptRho && !(p->fctrRho > 0)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "fctrRho must be positive");
+    return QPS_OK;
+}
+
+SolverBase* make_dense(int device, int64_t n, int64_t m, int dtype, const double* P, int64_t ldp, const double* A, int64_t lda,
+                       const double* q, const double* l, const double* u) {
+    if (dtype == QPS_F64) {
+        auto* s = new DenseSolver<double>(device, n, m, dtype);
+        try {
+            s->upload_matrix(P, ldp, (int)n, (int)n, s->P, s->NP);
+            s->upload_matrix(A, lda, (int)m, (int)n, s->A, s->NP);
+            s->upload_vec(q, s->q, n); s->upload_vec(l, s->l, m); s->upload_vec(u, s->u, m);
+        } catch (...) { delete s; throw; }
+        return s;
+    }
+    auto* s = new DenseSolver<float>(device, n, m, dtype);
+    try {
+        s->upload_matrix(P, ldp, (int)n, (int)n, s->P, s->NP);
+        s->upload_matrix(A, lda, (int)m, (int)n, s->A, s->NP);
+        s->upload_vec(q, s->q, n); s->upload_vec(l, s->l, m); s->upload_vec(u, s->u, m);
+    } catch (...) { delete s; throw; }
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define QPS_API __attribute__((visibility("default")))
+
+QPS_API int32_t qps_default_params(qps_params* p) {
+    if (!p) return QPS_ERR_BAD_ARGUMENT;
+    memset(p, 0, sizeof(*p));
+    p->numIterations = 5000; p->epsAbs = 1e-6; p->epsRel = 1e-6;            // SolveQuadraticProgram.jl:15
+    p->rho = 1.0; p->sigma = 1e-6; p->alpha = 1.6; p->delta = 1e-6; p->adptRho = 0;   // :16
+    p->fctrRho = 5.0; p->numItrConv = 25; p->numItrPolish = 10; p->epsMinres = 1e-6; p->numItrMinres = 500;   // :17
+    p->linsys = QPS_LINSYS_AUTO; p->trsvBlock = 0; p->reuseFactor = 0;
+    p->epsPcg = 1e-6; p->numItrPcg = 1000;                                  // LinearSystemSolvers.jl:125
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+QPS_API int32_t qps_create_dense(int64_t n, int64_t m, const double* P, int64_t ldp, const double* A, int64_t lda,
+                                 const double* q, const double* l, const double* u, int32_t dtype, int32_t device,
+                                 qps_handle* out) {
+    if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
+    *out = nullptr;
+    if (n <= 0 || m < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1 and m >= 0");
+    if (n > (1 << 20) || m > (1 << 24)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "dense problem too large");
+    if (!P || !q || (m > 0 && (!A || !l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
+    if (ldp < n || (m > 0 && lda < m)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "leading dimension smaller than the row count");
+    if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
+    for (int64_t j = 0; j < n; ++j) if (!all_finite(P + j * ldp, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P contains NaN/Inf");
+    for (int64_t j = 0; j < n && m > 0; ++j) if (!all_finite(A + j * lda, m, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "A contains NaN/Inf");
+    if (!all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "q contains NaN/Inf");
+    if (m > 0 && (!all_finite(l, m, true) || !all_finite(u, m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
+    Handle* h = new Handle(); h->n = n; h->m = m;
+    int rc = guarded(nullptr, [&] { h->impl = make_dense(device, n, m, dtype, P, ldp, A, lda, q, l, u); });
+    if (rc != QPS_OK) { delete h; return rc; }
+    *out = reinterpret_cast<qps_handle>(h);
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_create_csc(int64_t n, int64_t m, const int64_t* Pcp, const int64_t* Pri, const double* Pnz,
+                               const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* q, const double* l,
+                               const double* u, int32_t index_base, int32_t dense_path, int32_t dtype, int32_t device,
+                               qps_handle* out) {
+    if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
+    *out = nullptr;
+    if (n <= 0 || m < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1 and m >= 0");
+    if (!Pcp || !q || !Acp || (m > 0 && (!l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
+    if (index_base != 0 && index_base != 1) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "index_base must be 0 or 1");
+    if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
+    const int64_t pnnz = Pcp[n] - index_base, annz = Acp[n] - index_base;
+    if (Pcp[0] != index_base || Acp[0] != index_base || pnnz < 0 || annz < 0) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr does not start at index_base");
+    for (int64_t j = 0; j < n; ++j) if (Pcp[j + 1] < Pcp[j] || Acp[j + 1] < Acp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr not monotone");
+    for (int64_t k = 0; k < pnnz; ++k) if (Pri[k] - index_base < 0 || Pri[k] - index_base >= n) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "P row index out of range");
+    for (int64_t k = 0; k < annz; ++k) if (Ari[k] - index_base < 0 || Ari[k] - index_base >= m) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "A row index out of range");
+    if (!all_finite(Pnz, pnnz, false) || !all_finite(Anz, annz, false) || !all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P/A/q contain NaN/Inf");
+    if (m > 0 && (!all_finite(l, m, true) || !all_finite(u, m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
+    Handle* h = new Handle(); h->n = n; h->m = m;
+    int rc;
+    if (dense_path) {
+        if ((double)n * n > 4e9 || (double)m * n > 8e9) { delete h; return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "problem too large to densify"); }
+        rc = guarded(nullptr, [&] {
+            std::vector<double> Pd((size_t)n * n, 0.0), Ad((size_t)std::max<int64_t>(m, 1) * n, 0.0);
+            for (int64_t j = 0; j < n; ++j) {
+                for (int64_t k = Pcp[j] - index_base; k < Pcp[j + 1] - index_base; ++k) Pd[(size_t)(Pri[k] - index_base) + (size_t)j * n] += Pnz[k];
+                for (int64_t k = Acp[j] - index_base; k < Acp[j + 1] - index_base; ++k) Ad[(size_t)(Ari[k] - index_base) + (size_t)j * m] += Anz[k];
+            }
+            h->impl = make_dense(device, n, m, dtype, Pd.data(), n, Ad.data(), std::max<int64_t>(m, 1), q, l, u);
+        });
+    } else {
+        rc = guarded(nullptr, [&] { h->impl = make_sparse_solver(device, n, m, dtype, Pcp, Pri, Pnz, Acp, Ari, Anz, q, l, u, index_base); });
+    }
+    if (rc != QPS_OK) { delete h; return rc; }
+    *out = reinterpret_cast<qps_handle>(h);
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_solve(qps_handle hh, double* x, const qps_params* p, qps_info* info) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (!x) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "x_inout is NULL");
+    int rc = validate_params(h, p);
+    if (rc != QPS_OK) return rc;
+    if (!all_finite(x, h->n, false)) return fail_with(h, QPS_ERR_NOT_FINITE, "x_inout (warm start) contains NaN/Inf");
+    return guarded(h, [&] { h->impl->solve(x, *p, info); });
+}
+
+QPS_API int32_t qps_get_dual(qps_handle hh, double* z, double* y) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    return guarded(h, [&] { h->impl->get_dual(z, y); });
+}
+
+QPS_API int32_t qps_linsys_init(qps_handle hh, double rho, double sigma, int32_t linsys, int32_t trsvBlock) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (!(rho > 0) || !(sigma >= 0)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "rho must be positive, sigma non-negative");
+    return guarded(h, [&] { h->impl->linsys_init(rho, sigma, linsys, trsvBlock); });
+}
+
+QPS_API int32_t qps_linsys_solve(qps_handle hh, const double* x, const double* z, const double* y, double rho, double sigma,
+                                 int32_t changed, double* xx, double* zz) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (!x || !xx || (h->m > 0 && (!z || !y || !zz))) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "NULL vector");
+    if (!(rho > 0) || !(sigma >= 0)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "rho must be positive, sigma non-negative");
+    return guarded(h, [&] { h->impl->linsys_solve(x, z, y, rho, sigma, changed, xx, zz); });
+}
+
+QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, const double* P, const double* A, const double* q,
+                                       const double* l, const double* u, int32_t dtype, int32_t device, qps_handle* out) {
+    if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
+    *out = nullptr;
+    if (count <= 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "batch count must be positive");
+    Handle* h = new Handle(); h->n = n; h->m = m;
+    for (int64_t b = 0; b < count; ++b) {
+        qps_handle one = nullptr;
+        int rc = qps_create_dense(n, m, P + b * n * n, n, A ? A + b * m * n : nullptr, m, q + b * n, l ? l + b * m : nullptr,
+                                  u ? u + b * m : nullptr, dtype, device, &one);
+        if (rc != QPS_OK) { for (auto* s : h->batch) delete s; delete h; return rc; }
+        Handle* oh = reinterpret_cast<Handle*>(one);
+        h->batch.push_back(oh->impl); oh->impl = nullptr; delete oh;
+    }
+    *out = reinterpret_cast<qps_handle>(h);
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_solve_batch(qps_handle hh, double* x, const qps_params* p, qps_info* infos) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || h->batch.empty()) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a batch handle");
+    int rc = validate_params(h, p);
+    if (rc != QPS_OK) return rc;
+    for (size_t b = 0; b < h->batch.size(); ++b) {
+        rc = guarded(h, [&] { h->batch[b]->solve(x + (int64_t)b * h->n, *p, infos ? infos + b : nullptr); });
+        if (rc != QPS_OK) return rc;
+    }
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_set_profiling(qps_handle hh, int32_t on) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h) return QPS_ERR_BAD_ARGUMENT;
+    if (h->impl) h->impl->prof.level = on;
+    for (auto* s : h->batch) s->prof.level = on;
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_kernel_times(qps_handle hh, qps_kernel_time* out, int32_t cap, int32_t* count) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !count) return QPS_ERR_BAD_ARGUMENT;
+    SolverBase* s = h->impl ? h->impl : (h->batch.empty() ? nullptr : h->batch[0]);
+    if (!s) return QPS_ERR_BAD_ARGUMENT;
+    int k = 0;
+    for (size_t i = 0; i < s->prof.names.size() && k < cap; ++i) {
+        if (s->prof.stats[i].launches == 0) continue;
+        if (out) {
+            memset(&out[k], 0, sizeof(out[k]));
+            strncpy(out[k].name, s->prof.names[i].c_str(), sizeof(out[k].name) - 1);
+            out[k].seconds = s->prof.stats[i].seconds; out[k].launches = s->prof.stats[i].launches; out[k].algo_bytes = s->prof.stats[i].algo_bytes;
+        }
+        ++k;
+    }
+    *count = k;
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_destroy(qps_handle hh) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h) return QPS_OK;
+    delete h->impl;
+    for (auto* s : h->batch) delete s;
+    delete h;
+    return QPS_OK;
+}
+
+QPS_API const char* qps_last_error(qps_handle hh) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (h) return h->err.c_str();
+    return g_last_error.c_str();
+}
+
+QPS_API const char* qps_version(void) { return "qps-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

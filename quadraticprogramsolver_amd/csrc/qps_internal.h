@@ -1,0 +1,90 @@
+// qps_internal.h -- shared host-side plumbing of libqps_hip (not part of the public boundary).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qps.h"
+
+namespace qps {
+
+struct QpsError { int code; std::string msg; QpsError(int c, std::string m) : code(c), msg(std::move(m)) {} };
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline int roundup(int64_t v, int q) { return (int)(((v + q - 1) / q) * q); }
+
+struct KernelStat { double seconds = 0; int64_t launches = 0; double algo_bytes = 0; };
+
+// Brackets launches of one category with HIP events on the solver stream; elapsed times are harvested at the next
+// host synchronisation (every numItrConv iterations), so the loop itself is not stalled.
+struct Profiler {
+    int level = 0;
+    hipStream_t st = nullptr;
+    struct Pending { int cat; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    std::vector<std::string> names;
+    std::vector<KernelStat> stats;
+    int category(const char* name, double bytes) {
+        for (size_t i = 0; i < names.size(); ++i) if (names[i] == name) return (int)i;
+        names.push_back(name); KernelStat s; s.algo_bytes = bytes; stats.push_back(s); return (int)names.size() - 1;
+    }
+    hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; (void)hipEventCreate(&e); return e; }
+    bool on(int cat_level) const { return level >= cat_level; }
+    void begin(int cat, hipEvent_t& a) { a = get(); (void)hipEventRecord(a, st); (void)cat; }
+    void end(int cat, hipEvent_t a) { hipEvent_t b = get(); (void)hipEventRecord(b, st); pending.push_back({cat, a, b}); }
+    void harvest() {   // call after a stream synchronisation
+        for (auto& p : pending) {
+            float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
+            stats[p.cat].seconds += ms * 1e-3; stats[p.cat].launches += 1;
+            pool.push_back(p.a); pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    void reset() { for (auto& s : stats) { s.seconds = 0; s.launches = 0; } }
+    ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } }
+};
+struct ProfScope {
+    Profiler& p; int cat; hipEvent_t a; bool active;
+    ProfScope(Profiler& pr, int c, int lvl) : p(pr), cat(c), a(nullptr), active(pr.on(lvl)) { if (active) p.begin(cat, a); }
+    ~ProfScope() { if (active) p.end(cat, a); }
+};
+
+#define HIPC(expr)                                                                                            \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw QpsError(e_ == hipErrorOutOfMemory ? QPS_ERR_OUT_OF_MEMORY : QPS_ERR_HIP, b_);               \
+        }                                                                                                     \
+    } while (0)
+
+template <typename T> inline T* dalloc(int64_t count) {
+    T* p = nullptr; if (count < 64) count = 64;
+    HIPC(hipMalloc((void**)&p, sizeof(T) * (size_t)count));
+    HIPC(hipMemset(p, 0, sizeof(T) * (size_t)count));
+    return p;
+}
+
+struct SolverBase {
+    int device = 0; hipStream_t st = nullptr; int dtype = 0; int64_t n = 0, m = 0; bool sparse = false;
+    std::string err; Profiler prof;
+    virtual ~SolverBase() {}
+    virtual void solve(double* x, const qps_params& p, qps_info* info) = 0;
+    virtual void get_dual(double* z, double* y) = 0;
+    virtual void linsys_init(double rho, double sigma, int linsys, int nb) = 0;
+    virtual void linsys_solve(const double* x, const double* z, const double* y, double rho, double sigma, int changed,
+                              double* xx, double* zz) = 0;
+};
+
+
+SolverBase* make_sparse_solver(int device, int64_t n, int64_t m, int dtype, const int64_t* Pcp, const int64_t* Pri,
+                               const double* Pnz, const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* q,
+                               const double* l, const double* u, int index_base);
+
+}  // namespace qps

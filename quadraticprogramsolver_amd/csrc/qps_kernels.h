@@ -1,0 +1,80 @@
+// qps_kernels.h -- host-callable launchers of the gfx950 kernels (internal; the public boundary is include/qps.h).
+//
+// Device data layout (dense path), all in HBM, T = double or float:
+//   A   : m x n, ROW-major, leading dimension NP = roundup(n, 64), MP = roundup(m, 64) rows allocated, zero padded.
+//   P   : n x n symmetric, row-major (== column-major), ld NP, zero padded.
+//   S   : NP x NP "sweep matrix": lower triangle = W, upper triangle = W' where W is the Cholesky factor L of
+//         M = P + sigma I + rho A'A with its nb x nb diagonal blocks replaced by their inverses.  Both triangular
+//         sweeps are then row-dot-product GEMVs over S (forward reads c <= r, backward reads c >= r).
+//   vectors of length n / m are allocated NP / MP long and zero padded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qps {
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { using type = double2; static constexpr int N = 2; };
+template <> struct VecOf<float>  { using type = float4;  static constexpr int N = 4; };
+
+// ---- loop kernels (k_loop.hip) -------------------------------------------------------------------------------
+// out[r] = alpha * sum_{c in [c0,c1), tri} S[r][c] v[c] + beta * out0[r]   for r in [r0, r1); tri: 0 none, 1 c<=r, 2 c>=r
+template <typename T>
+void gemv_rows(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta,
+               int r0, int r1, int c0, int c1, int tri);
+
+// part[t][c] = sum_{r in row tile t} S[r][c] * (ca*va[r] + cb*vb[r])  for c in [0, ncols); returns number of tiles
+template <typename T>
+int gemv_cols_partial(hipStream_t st, const T* S, int64_t ld, const T* va, const T* vb, T ca, T cb,
+                      T* part, int64_t part_ld, int nrows, int ncols);
+int gemv_cols_tiles(int nrows);
+
+// out[c] = s0*a0[c] + s1*a1[c] + sum_{t<ntiles} part[t][c]
+template <typename T>
+void colsum(hipStream_t st, const T* part, int64_t part_ld, int ntiles, const T* a0, T s0, const T* a1, T s1,
+            T* out, int ncols);
+
+// SolveQuadraticProgram.jl:56-61 fused: xp=x; x=alpha*xx+(1-alpha)*x; zp=z; z=clamp(...); y=y+rho*(...)
+template <typename T>
+void admm_update(hipStream_t st, int NP, int MP, const T* xx, const T* zz, T* x, T* xp, T* z, T* zp, T* y,
+                 const T* l, const T* u, T alpha, T rho);
+
+// SolveQuadraticProgram.jl:79-112: norms + decision.  Ax, Px, Aty are precomputed by GEMVs.  res = 16 doubles:
+//  [0] resPrim [1] resDual [2] maxNormPrim [3] maxNormDual [4] rhorho [5] convFlag [6] dx [7] dz
+struct CheckScalars { double epsAbs, epsRel, epsAdmm, rho, rhorho; int adptRho; int convFlag; };
+template <typename T>
+void check_convergence(hipStream_t st, int n, int m, const T* Ax, const T* Px, const T* Aty, const T* q, const T* x,
+                       const T* xp, const T* z, const T* zp, unsigned long long* scratch /*>=16 u64*/, double* res_dev,
+                       CheckScalars cs);
+
+template <typename T> void fill(hipStream_t st, T* p, int64_t n, T v);
+template <typename T> void convert_copy(hipStream_t st, const double* src, T* dst, int64_t n);   // dst[i] = (T)src[i]
+template <typename T> void convert_back(hipStream_t st, const T* src, double* dst, int64_t n);   // dst[i] = (double)src[i]
+
+// ---- setup kernels (k_setup.hip) -----------------------------------------------------------------------------
+// dst (row-major rows x NPc, zero padded to rowsP x NPc) = transpose-of-column-major src (rows x cols, ld lds) as T
+template <typename T>
+void import_colmajor(hipStream_t st, const double* src, int64_t lds, int rows, int cols, T* dst, int64_t ldd);
+
+// C[i][j] (+)= alpha * sum_k opA(i,k) opB(k,j); all dims multiples of 64 (K multiple of 16); row-major C with ldc.
+// a_kcontig: opA(i,k) = A[i*lda + k] else A[k*lda + i].  b_kcontig: opB(k,j) = B[j*ldb + k] else B[k*ldb + j].
+// lower_only: skip tiles strictly above the block diagonal.  batch: blockIdx.z with element strides sA,sB,sC.
+template <typename T>
+void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda, bool a_kcontig, const T* B, int64_t ldb,
+          bool b_kcontig, T beta, T* C, int64_t ldc, bool lower_only, int batch = 1, int64_t sA = 0, int64_t sB = 0,
+          int64_t sC = 0);
+
+// M = PI + rho * AA (lower triangle incl. diagonal tiles; NP x NP)   (LinearSystemSolvers.jl:114,128)
+template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M);
+// PI = P + sigma I on the n x n part, identity on the padding diagonal (keeps the padded factor well defined)
+template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI);
+
+// Blocked right-looking Cholesky of the NP x NP row-major matrix M (lower), in place.  dinv receives the inverses of
+// the 64 x 64 diagonal blocks (NP/64 blocks of 64*64).  fail_dev: int32, 0 or 1+index of the failing pivot.
+template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev);
+
+// Build the sweep matrix S from L (lower of M) and the 64-block inverses: diagonal nb-blocks inverted by recursive
+// doubling, then mirrored into the upper triangle.  tmp: NP x NP scratch.
+template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp);
+
+}  // namespace qps

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference interface for the ADMM QP path, driving libqps_hip.so through its C ABI.
+
+Reference (file:line under RoyiAvital/QuadraticProgramSolver):
+  SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, LinSysSolInit, LinSysSol!; kw...)   SolveQuadraticProgram.jl:14-76
+  @enum LinearSolverMode / ConvergenceFlag                                          SolveQuadraticProgram.jl:11-12
+  plugin pair Init / Sol!                                                            LinearSystemSolvers.jl:16-229
+
+Python cannot spell ``!`` in an identifier, so the mutating function is ``SolveQuadraticProgramInplace`` (alias
+``SolveQuadraticProgram_b``); positional order, keyword names (including the Unicode ones) and the returned enum are
+the reference's.  The Julia ``ccall`` wrapper that keeps the exact spelling lives in julia/QuadraticProgramSolverHIP.jl.
+
+Passing the sentinel pair ``(HipCholInit, HipChol)`` (dense reduced-form Cholesky) or ``(HipCgInit, HipCg)`` (CSR
+matrix-free CG) routes the whole loop to the device-resident implementation.  The pairs are also callable literally
+with the reference plugin signature (host vectors in, device solve, host vectors out) so that an unmodified
+reference-style loop can drive the GPU linear solve.  There is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import QPS_F32, QPS_F64, QPS_LINSYS_AUTO, QPS_LINSYS_CG, QPS_LINSYS_CHOLESKY, QpsInfo
+
+
+class LinearSolverMode(enum.IntEnum):
+    """SolveQuadraticProgram.jl:11 (the reference's spelling ``modeItertaive`` is kept)."""
+    modeAuto = 1
+    modeItertaive = 2
+    modeDirect = 3
+
+
+class ConvergenceFlag(enum.IntEnum):
+    """SolveQuadraticProgram.jl:12"""
+    convNumItr = 1
+    convAdmm = 2
+    convPrimDual = 3
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _vec(v, name, length=None):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+    if length is not None and a.shape[0] != length:
+        raise ValueError(f"dimension mismatch: {name} has {a.shape[0]} elements, expected {length}")
+    return a
+
+
+def _validate_dims(numElementsX, mP, vQ, mA, vL, vU):
+    """The reference Julia loop never validates (SolveQuadraticProgram.jl:19-24); the MATLAB original does
+    (SolveQuadraticProgram.m:158-184) and this mirrors those checks."""
+    if mP.shape[0] != mP.shape[1]:
+        raise ValueError("The matrix mP must be square")
+    if mP.shape[0] != numElementsX:
+        raise ValueError("The matrix mP dimensions must match the vector vX")
+    if np.asarray(vQ).reshape(-1).shape[0] != numElementsX:
+        raise ValueError("The vector vQ dimensions must match the vector vX")
+    if mA.shape[1] != numElementsX:
+        raise ValueError("The number of columns of mA must match the vector vX")
+    if np.asarray(vL).reshape(-1).shape[0] != mA.shape[0] or np.asarray(vU).reshape(-1).shape[0] != mA.shape[0]:
+        raise ValueError("The vectors vL, vU dimensions must match the rows of mA")
+
+
+class QuadraticProgram:
+    """A problem resident in HBM (qps_create_dense / qps_create_csc ... qps_destroy).
+
+    ``linsys``: "cholesky" (dense reduced form; sparse inputs are densified on the device) or "cg" (CSR, matrix-free).
+    """
+
+    def __init__(self, mP, vQ, mA, vL, vU, *, linsys="cholesky", dtype="f64", device=0):
+        n = mP.shape[0]
+        m = mA.shape[0]
+        _validate_dims(n, mP, vQ, mA, vL, vU)
+        self.n, self.m = n, m
+        self.linsys = {"cholesky": QPS_LINSYS_CHOLESKY, "cg": QPS_LINSYS_CG, "auto": QPS_LINSYS_AUTO}[linsys]
+        dt = {"f64": QPS_F64, "f32": QPS_F32}[dtype]
+        q, l, u = _vec(vQ, "vQ", n), _vec(vL, "vL", m), _vec(vU, "vU", m)
+        h = C.c_void_p()
+        L = _lib.lib()
+        if sp.issparse(mP) or sp.issparse(mA) or linsys == "cg":
+            Pc = sp.csc_matrix(mP, dtype=np.float64)
+            Ac = sp.csc_matrix(mA, dtype=np.float64)
+            Pc.sum_duplicates()
+            Ac.sum_duplicates()
+            Pcp, Pri, Pnz = Pc.indptr.astype(np.int64), Pc.indices.astype(np.int64), np.ascontiguousarray(Pc.data)
+            Acp, Ari, Anz = Ac.indptr.astype(np.int64), Ac.indices.astype(np.int64), np.ascontiguousarray(Ac.data)
+            st = L.qps_create_csc(n, m, _ip(Pcp), _ip(Pri), _dp(Pnz), _ip(Acp), _ip(Ari), _dp(Anz), _dp(q), _dp(l), _dp(u),
+                                  0, 0 if linsys == "cg" else 1, dt, device, C.byref(h))
+        else:
+            Pd = np.asfortranarray(mP, dtype=np.float64)
+            Ad = np.asfortranarray(mA, dtype=np.float64)
+            st = L.qps_create_dense(n, m, _dp(Pd), max(n, 1), _dp(Ad), max(m, 1), _dp(q), _dp(l), _dp(u), dt, device, C.byref(h))
+        _lib.check(st)
+        self._h = h
+
+    # -- SolveQuadraticProgram! -----------------------------------------------------------------------------------
+    def solve(self, vX, *, numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=False, fctrΡ=5,
+              numItrConv=25, numItrPolish=10, ϵMinres=1e-6, numItrMinres=500, ϵPcg=1e-6, numItrPcg=1000,
+              trsvBlock=0, reuseFactor=False, info=None):
+        """Mutates ``vX`` (warm start in, solution out) and returns the ConvergenceFlag."""
+        if not isinstance(vX, np.ndarray) or vX.dtype != np.float64 or not vX.flags.c_contiguous or vX.shape != (self.n,):
+            raise ValueError("vX must be a contiguous float64 vector of length numElements (it is updated in place)")
+        p = _lib.default_params()
+        p.numIterations, p.epsAbs, p.epsRel = int(numIterations), float(ϵAbs), float(ϵRel)
+        p.rho, p.sigma, p.alpha, p.delta = float(ρ), float(σ), float(α), float(δ)
+        p.adptRho, p.fctrRho, p.numItrConv = int(bool(adptΡ)), float(fctrΡ), int(numItrConv)
+        p.numItrPolish, p.epsMinres, p.numItrMinres = int(numItrPolish), float(ϵMinres), int(numItrMinres)
+        p.epsPcg, p.numItrPcg = float(ϵPcg), int(numItrPcg)
+        p.linsys, p.trsvBlock, p.reuseFactor = self.linsys, int(trsvBlock), int(bool(reuseFactor))
+        inf = QpsInfo()
+        _lib.check(_lib.lib().qps_solve(self._h, _dp(vX), C.byref(p), C.byref(inf)), self._h)
+        if info is not None:
+            info.update(inf.as_dict())
+        return ConvergenceFlag(inf.convFlag)
+
+    def dual(self):
+        """(z, y) of the last solve (additive: the reference discards them)."""
+        z = np.zeros(max(self.m, 1))
+        y = np.zeros(max(self.m, 1))
+        _lib.check(_lib.lib().qps_get_dual(self._h, _dp(z), _dp(y)), self._h)
+        return z[:self.m], y[:self.m]
+
+    # -- the literal plugin pair ------------------------------------------------------------------------------------
+    def linsys_init(self, ρ, σ, trsvBlock=0):
+        _lib.check(_lib.lib().qps_linsys_init(self._h, float(ρ), float(σ), self.linsys, int(trsvBlock)), self._h)
+
+    def linsys_solve(self, vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ):
+        x, z, y = _vec(vX, "vX", self.n), _vec(vZ, "vZ", self.m), _vec(vY, "vY", self.m)
+        xx = np.zeros(self.n)
+        zz = np.zeros(max(self.m, 1))
+        _lib.check(_lib.lib().qps_linsys_solve(self._h, _dp(x), _dp(z), _dp(y), float(ρ), float(σ), int(bool(changedΡ)),
+                                               _dp(xx), _dp(zz)), self._h)
+        vXX[:] = xx
+        vZZ[:] = zz[:self.m]
+
+    # -- profiling ----------------------------------------------------------------------------------------------------
+    def set_profiling(self, level: int):
+        _lib.check(_lib.lib().qps_set_profiling(self._h, int(level)), self._h)
+
+    def kernel_times(self):
+        buf = (_lib.QpsKernelTime * 32)()
+        cnt = C.c_int32(0)
+        _lib.check(_lib.lib().qps_kernel_times(self._h, buf, 32, C.byref(cnt)), self._h)
+        return [dict(name=buf[i].name.decode(), seconds=buf[i].seconds, launches=buf[i].launches, algo_bytes=buf[i].algo_bytes)
+                for i in range(cnt.value)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().qps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Plugin pairs with the reference signature (LinearSystemSolvers.jl:16,28)
+# ------------------------------------------------------------------------------------------------------------------
+def _make_pair(linsys: str, dtype: str = "f64"):
+    def Init(vX, mP, vQ, mA, ρ, ρ1, σ, numElements, numConstraints):
+        # vL/vU are not part of the plugin signature and the linear solve does not need them
+        prob = QuadraticProgram(mP, vQ, mA, np.zeros(numConstraints), np.zeros(numConstraints), linsys=linsys, dtype=dtype)
+        prob.linsys_init(ρ, σ)
+        vXX = np.zeros(numElements)
+        vZZ = np.zeros(numConstraints)
+        return vXX, vZZ, [prob]
+
+    def Sol(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ1, σ, numElements, numConstraints, changedΡ):
+        tuSolver[0].linsys_solve(vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ)
+
+    Init._qps_linsys = Sol._qps_linsys = linsys
+    Init._qps_dtype = Sol._qps_dtype = dtype
+    return Init, Sol
+
+
+HipCholInit, HipChol = _make_pair("cholesky")
+HipCgInit, HipCg = _make_pair("cg")
+HipCholF32Init, HipCholF32 = _make_pair("cholesky", "f32")
+
+
+def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholInit, LinSysSol=HipChol, *,
+                                 numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=False,
+                                 fctrΡ=5, numItrConv=25, numItrPolish=10, ϵMinres=1e-6, numItrMinres=500, info=None,
+                                 device=0, trsvBlock=0):
+    """``SolveQuadraticProgram!`` (SolveQuadraticProgram.jl:14-76): mutates ``vX``, returns the ConvergenceFlag.
+
+    ``δ, numItrPolish, ϵMinres, numItrMinres`` are accepted and ignored, as in the reference (:16-17, no polish).
+    ``info`` (optional dict) receives iterations, final ρ, residuals, timings -- additive."""
+    linsys = getattr(LinSysSolInit, "_qps_linsys", None)
+    if linsys is None or getattr(LinSysSol, "_qps_linsys", None) != linsys:
+        raise TypeError("LinSysSolInit/LinSysSol must be one of this package's pairs (HipCholInit, HipChol) / "
+                        "(HipCgInit, HipCg): the device-resident loop has no CPU path")
+    with QuadraticProgram(mP, vQ, mA, vL, vU, linsys=linsys, dtype=LinSysSolInit._qps_dtype, device=device) as prob:
+        return prob.solve(vX, numIterations=numIterations, ϵAbs=ϵAbs, ϵRel=ϵRel, ρ=ρ, σ=σ, α=α, δ=δ, adptΡ=adptΡ,
+                          fctrΡ=fctrΡ, numItrConv=numItrConv, numItrPolish=numItrPolish, ϵMinres=ϵMinres,
+                          numItrMinres=numItrMinres, trsvBlock=trsvBlock, info=info)
+
+
+SolveQuadraticProgram_b = SolveQuadraticProgramInplace
+
+
+def SolveQuadraticProgram(mP, vQ, mA, vL, vU, *, linearSolverMode=LinearSolverMode.modeAuto, **kw):
+    """Convenience form spelled in BASELINE.json's north_star: ``SolveQuadraticProgram(P, q, A, l, u; ...) -> (x, flag)``.
+
+    ``modeAuto`` follows the reference rule (SolveQuadraticProgram.jl:143-151: direct when the problem is small and not
+    too dense) re-scaled for HBM: dense Cholesky while the n x n factor is cheap to hold, CSR/CG beyond."""
+    mode = LinearSolverMode(linearSolverMode)
+    n = mP.shape[0]
+    if mode == LinearSolverMode.modeAuto:
+        mode = LinearSolverMode.modeDirect if n <= 16384 else LinearSolverMode.modeItertaive
+    pair = (HipCholInit, HipChol) if mode == LinearSolverMode.modeDirect else (HipCgInit, HipCg)
+    vX = np.zeros(n)
+    flag = SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, *pair, **kw)
+    return vX, flag
