@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/sec of the device-resident loop on BASELINE.json's headline config
+(dense n = 4096, m = 8192, fp64, one QP per GPU; ranks run independent replicas, no data-path collective).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one qps_solve() of --iters ADMM iterations (ϵAbs = ϵRel = 0, adptΡ off, reference defaults otherwise) on a
+problem already resident in HBM with its factorisation cached (setup is reported separately).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+HBM_ACHIEVABLE_GBS = 6290.0
+
+CONFIGS = {
+    "c2": dict(n=4096, m=8192, dtype="f64", label="dense n=4096 m=8192 fp64 single QP (BASELINE configs[1])"),
+    "c5": dict(n=4096, m=8192, dtype="f32", label="dense n=4096 m=8192 fp32, rho-update + refactor every 50 its (configs[4])"),
+    "c1": dict(n=64, m=128, dtype="f64", label="dense n=64 m=128 fp64 (configs[0] shape, plumbing)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=100, help="ADMM iterations per step")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--trsv-block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-time-to-eps", action="store_true")
+    ap.add_argument("--profile-level", type=int, default=1, help="1: HIP-event bracket the dominant kernel only; 2: all")
+    args = ap.parse_args()
+
+    import torch  # first: keeps a single HIP runtime in the process (torch bundles its own libamdhip64)
+    import numpy as np
+    import quadraticprogramsolver_amd as qps
+    from quadraticprogramsolver_amd import dist as qd
+
+    info = qd.rank_info_from_env()
+    if info.world_size != args.gpus and info.world_size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}")
+    backend = qd.init_process_group(info)
+    cfg = CONFIGS[args.config]
+    n, m = cfg["n"], cfg["m"]
+    s = 8 if cfg["dtype"] == "f64" else 4
+
+    # synthetic input: randomQp at density 1.0, seed 1234, one independent stream per rank (weak scaling)
+    P, q, A, l, u = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank)
+    device = info.local_rank if torch.cuda.device_count() > info.local_rank else 0
+    prob = qps.QuadraticProgram(P, q, A, l, u, dtype=cfg["dtype"], device=device)
+    solve_kw = dict(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, trsvBlock=args.trsv_block, reuseFactor=True)
+    if args.config == "c5":
+        solve_kw.update(adptΡ=True, fctrΡ=1.0, numItrConv=50, ρ=0.1)   # ρ proposal applied (=> refactor) at every check
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    setup_info = {}
+    x = np.zeros(n)
+    prob.solve(x, **dict(solve_kw, numIterations=min(args.iters, 25), reuseFactor=False), info=setup_info)   # builds + caches the factor
+    for _ in range(args.warmup):
+        x = np.zeros(n)
+        prob.solve(x, **solve_kw)
+    prob.set_profiling(args.profile_level)
+    iters_done = 0
+    loop_device_s = 0.0
+    qd.barrier(info); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = np.zeros(n); si = {}
+        prob.solve(x, **solve_kw, info=si)
+        iters_done += si["iterations"]; loop_device_s += si["tLoop"]
+    sync(); qd.barrier(info)
+    elapsed = time.perf_counter() - t0
+    ktimes = prob.kernel_times()   # HIP-event times accumulated over the timed steps (reset by set_profiling)
+    prob.set_profiling(0)
+    value, tmax = qd.gather_timings(info, elapsed, iters_done)
+
+    out = None
+    if info.rank == 0:
+        b_iter = s * (m * n + n * n) + s * (6 * n + 10 * m)       # SURVEY §8d algorithmic bytes per ADMM iteration
+        dom = max(ktimes, key=lambda k: k["seconds"]) if ktimes else None
+        roofline = None
+        if dom:
+            dur = dom["seconds"] / dom["launches"]
+            ach = dom["algo_bytes"] / dur / 1e9
+            roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(dur * 1e6, 2),
+                        "algo_bytes_per_launch": dom["algo_bytes"], "launches_timed": dom["launches"]}
+        per_gpu = value / info.world_size
+        out = {
+            "metric": "ADMM iterations/sec", "value": round(value, 2), "unit": "iterations/s", "n_gpus": info.world_size,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["label"], "n": n, "m": m, "admm_iterations_per_step": args.iters,
+                       "qps_per_gpu": 1, "parallelism": f"replicas x{info.world_size} (independent QPs, no collective)",
+                       "params": "eps=0, adptRho off, rho=1, sigma=1e-6, alpha=1.6, numItrConv=25 (SolveQuadraticProgram.jl:15-17)"
+                                 if args.config != "c5" else "fp32, adptRho on, fctrRho=1, numItrConv=50 (refactor at every check)",
+                       "dist_backend": backend},
+            "roofline": roofline,
+            "loop_roofline": {"algo_bytes_per_iteration": b_iter, "achieved_GBs": round(b_iter * per_gpu / 1e9, 1),
+                              "frac_of_8TBs": round(b_iter * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
+                              "frac_of_6.29TBs": round(b_iter * per_gpu / 1e9 / HBM_ACHIEVABLE_GBS, 4)},
+            "setup_ms": round(setup_info.get("tSetup", 0.0) * 1e3, 2),
+            "kernels": [{"name": k["name"], "avg_us": round(k["seconds"] / k["launches"] * 1e6, 2), "launches": k["launches"],
+                         "algo_GBs": round(k["algo_bytes"] / (k["seconds"] / k["launches"]) / 1e9, 1)} for k in ktimes],
+        }
+        if not args.no_time_to_eps and args.config == "c2":
+            # time-to-eps on the feasible variant (the plain m = 2n draw is primal infeasible: see generator docstring)
+            Pf, qf, Af, lf, uf = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank, feasible=True)
+            with qps.QuadraticProgram(Pf, qf, Af, lf, uf, dtype=cfg["dtype"], device=device) as pf:
+                xf = np.zeros(n); ti = {}
+                t1 = time.perf_counter()
+                flag = pf.solve(xf, numIterations=50000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True, trsvBlock=args.trsv_block, info=ti)
+                out["time_to_eps"] = {"eps": 1e-6, "rho0": 0.1, "adptRho": True, "flag": int(flag), "iterations": ti["iterations"],
+                                      "refactorisations": ti["numRefactor"], "ms_total": round((time.perf_counter() - t1) * 1e3, 2),
+                                      "ms_setup": round(ti["tSetup"] * 1e3, 2), "ms_loop": round(ti["tLoop"] * 1e3, 2),
+                                      "problem": "randomQp density 1.0, bounds centred on A*x0 (feasible variant)"}
+            del Pf, Af
+        if not args.no_cpu_baseline and info.world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(P, q, A, l, u, args.config)
+    prob.close()
+    if info.rank == 0:
+        print(json.dumps(out), flush=True)
+    if info.world_size > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(P, q, A, l, u, config):
+    """The oracle's C restatement (kind "port": the Julia reference cannot run in this pipeline) timed on this box's
+    host cores on a bounded sample of the same workload: the full setup + 50 iterations on all cores, then 10
+    iterations of the loop on one core (the reference loop and its LDL solves are single-threaded)."""
+    from oracle import c_oracle as co
+    cores = co.available_cores()   # min(affinity mask, cgroup CPU quota)
+    x, i_all = co.solve(P, q, A, l, u, numIterations=50, epsAbs=0.0, epsRel=0.0, numThreads=cores)
+    x, i_one = co.solve(P, q, A, l, u, numIterations=10, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1)
+    return {"value": round(50 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": "same C2 problem: full setup + 50 ADMM iterations on all cores (OpenMP over rows); "
+                      "single-thread loop rate from 10 more iterations",
+            "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(10 / i_one["tLoop"], 3),
+            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
+
+
+if __name__ == "__main__":
+    main()

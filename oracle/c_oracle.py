@@ -18,13 +18,37 @@ class OqParams(C.Structure):
     _fields_ = [("numIterations", C.c_int32), ("adptRho", C.c_int32), ("numItrConv", C.c_int32), ("linsys", C.c_int32),
                 ("epsAbs", C.c_double), ("epsRel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
                 ("alpha", C.c_double), ("fctrRho", C.c_double), ("epsPcg", C.c_double), ("numItrPcg", C.c_int32),
-                ("numThreads", C.c_int32)]
+                ("numThreads", C.c_int32), ("loopThreads", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OqInfo(C.Structure):
     _fields_ = [("convFlag", C.c_int32), ("iterations", C.c_int32), ("numRefactor", C.c_int32), ("cgIterations", C.c_int32),
                 ("rhoFinal", C.c_double), ("rhoProposed", C.c_double), ("resPrim", C.c_double), ("resDual", C.c_double),
                 ("maxNormPrim", C.c_double), ("maxNormDual", C.c_double), ("tSetup", C.c_double), ("tLoop", C.c_double)]
+
+
+def available_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  A GPU box exposes every host core
+    in the mask while the job's share is far smaller; OpenMP must not spawn a thread per visible core."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
 def build(force: bool = False) -> str:
@@ -41,6 +65,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(available_cores(), 16)))
         _lib = C.CDLL(_LIB_PATH)
         _lib.oq_version.restype = C.c_char_p
         _lib.oq_linsys_init_dense.restype = C.c_void_p
@@ -57,15 +83,17 @@ def _ip(a):
 
 
 def make_params(numIterations=5000, epsAbs=1e-6, epsRel=1e-6, rho=1.0, sigma=1e-6, alpha=1.6, adptRho=False, fctrRho=5.0,
-                numItrConv=25, linsys=KIND_RED_CHOL, epsPcg=1e-6, numItrPcg=1000, numThreads=0) -> OqParams:
+                numItrConv=25, linsys=KIND_RED_CHOL, epsPcg=1e-6, numItrPcg=1000, numThreads=0, loopThreads=0) -> OqParams:
     return OqParams(numIterations, int(bool(adptRho)), numItrConv, linsys, epsAbs, epsRel, float(rho), sigma, alpha,
-                    float(fctrRho), epsPcg, numItrPcg, numThreads)
+                    float(fctrRho), epsPcg, numItrPcg, numThreads, loopThreads, 0)
 
 
 def solve(mP, vQ, mA, vL, vU, vX=None, **kw):
     """Run the C restatement.  Dense (ndarray) or sparse (scipy) inputs.  Returns (x, info dict incl. z, y)."""
     n = mP.shape[0]
     m = mA.shape[0]
+    if not kw.get("numThreads"):
+        kw["numThreads"] = min(available_cores(), 16)
     prm = make_params(**kw)
     info = OqInfo()
     x = np.zeros(n) if vX is None else np.array(vX, dtype=np.float64)

@@ -35,6 +35,7 @@
 #endif
 
 #define OQ_EXPORT __attribute__((visibility("default")))
+#define OQ_PAR_MIN ((int64_t)1 << 18)   /* below this many multiply-adds a loop stays serial */
 
 /* SolveQuadraticProgram.jl:12  @enum ConvergenceFlag convNumItr = 1 convAdmm convPrimDual */
 enum { convNumItr = 1, convAdmm = 2, convPrimDual = 3 };
@@ -50,6 +51,8 @@ typedef struct {
     double epsPcg;           /* LinearSystemSolvers.jl:125 default 1e-6 */
     int32_t numItrPcg;       /* LinearSystemSolvers.jl:125 default 1000 */
     int32_t numThreads;      /* 0 = leave OpenMP default */
+    int32_t loopThreads;     /* 0 = same as numThreads; else thread count for the iteration loop only (setup keeps numThreads) */
+    int32_t reserved;
 } oq_params;
 
 typedef struct {
@@ -112,7 +115,7 @@ typedef struct {
 static void mul_A(const oq_prob *p, const double *x, double *y) { /* y[m] = A x */
     int64_t n = p->n, m = p->m;
     if (!p->sparse) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * m > OQ_PAR_MIN)
         for (int64_t i0 = 0; i0 < m; i0 += 256) {
             int64_t i1 = i0 + 256 < m ? i0 + 256 : m;
             for (int64_t i = i0; i < i1; ++i) y[i] = 0.0;
@@ -132,14 +135,14 @@ static void mul_A(const oq_prob *p, const double *x, double *y) { /* y[m] = A x 
 static void mul_At(const oq_prob *p, const double *v, double *y) { /* y[n] = A' v */
     int64_t n = p->n, m = p->m;
     if (!p->sparse) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * m > OQ_PAR_MIN)
         for (int64_t j = 0; j < n; ++j) {
             const double *col = p->A + j * m; double s = 0.0;
             for (int64_t i = 0; i < m; ++i) s += col[i] * v[i];
             y[j] = s;
         }
     } else {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (p->Acp[n] > OQ_PAR_MIN)
         for (int64_t j = 0; j < n; ++j) {
             double s = 0.0;
             for (int64_t k = p->Acp[j]; k < p->Acp[j + 1]; ++k) s += p->Anz[k] * v[p->Ari[k]];
@@ -151,14 +154,14 @@ static void mul_P(const oq_prob *p, const double *x, double *y) { /* y[n] = P x 
     int64_t n = p->n;
     if (!p->sparse) {
         /* P symmetric: row i of P == column i, so use contiguous columns for a dot product */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * n > OQ_PAR_MIN)
         for (int64_t i = 0; i < n; ++i) {
             const double *col = p->P + i * n; double s = 0.0;
             for (int64_t j = 0; j < n; ++j) s += col[j] * x[j];
             y[i] = s;
         }
     } else {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (p->Pcp[n] > OQ_PAR_MIN)
         for (int64_t j = 0; j < n; ++j) {
             double s = 0.0;
             for (int64_t k = p->Pcp[j]; k < p->Pcp[j + 1]; ++k) s += p->Pnz[k] * x[p->Pri[k]];
@@ -174,7 +177,7 @@ static void mul_P(const oq_prob *p, const double *x, double *y) { /* y[n] = P x 
  * LinearSystemSolvers.jl:112  mAA = mA' * mA */
 static void dense_AtA(int64_t m, int64_t n, const double *A, double *C) {
     const int64_t TB = 48;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (n * n * m > 64 * OQ_PAR_MIN)
     for (int64_t jb = 0; jb < n; jb += TB) {
         int64_t je = jb + TB < n ? jb + TB : n;
         for (int64_t ib = jb; ib < n; ib += TB) {
@@ -217,7 +220,7 @@ static int64_t dense_cholesky(int64_t n, double *M) {
         }
         /* trailing update: M[i,j] -= sum_{p in block} L[i,p] L[j,p], j >= ke, i >= j */
         int64_t nbk = ke - kb;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) if ((n - ke) * (n - ke) > OQ_PAR_MIN)
         for (int64_t j = ke; j < n; ++j) {
             double lj[64];
             for (int64_t p = 0; p < nbk; ++p) lj[p] = M[j + (kb + p) * n];
@@ -376,7 +379,7 @@ static void linsys_free(oq_linsys *s) {
 static void reduced_op(oq_linsys *s, double rho, double sigma, const double *w, double *u) {
     const oq_prob *p = s->p; int64_t n = p->n;
     if (s->kind == 2) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * n > OQ_PAR_MIN)
         for (int64_t i = 0; i < n; ++i) { const double *col = s->F + i * n; double acc = 0.0; for (int64_t j = 0; j < n; ++j) acc += col[j] * w[j]; u[i] = acc; }
     } else {
         mul_A(p, w, s->cg_tmp_m);
@@ -477,6 +480,9 @@ static int32_t solve_core(const oq_prob *p, const double *vQ, const double *vL, 
     double t0 = now_sec();
     oq_linsys *s = linsys_init(prm->linsys, p, rho, rho1, sigma, prm->epsPcg, prm->numItrPcg); /* :36 */
     double t1 = now_sec();
+#ifdef _OPENMP
+    if (prm->loopThreads > 0) omp_set_num_threads(prm->loopThreads);
+#endif
     if (s->fail) { info->convFlag = -(int32_t)s->fail; linsys_free(s); return -1; }
     size_t mm = (size_t)(m > 0 ? m : 1), nn = (size_t)(n > 0 ? n : 1);
     double *vXP = (double *)calloc(nn, sizeof(double));        /* :38 */

@@ -178,7 +178,6 @@ template <typename T> struct DenseSolver : SolverBase {
         const double t1 = now_s();
         double rhorho = rho;                                                                        // :43
         int ii = 0, nref = 0; double tref = 0, resP = NAN, resD = NAN;
-        prof.reset();
         for (ii = 1; ii <= p.numIterations; ++ii) {                                                 // :45
             if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {          // :47
                 rho = rhorho; ++nref;                                                               // :48-51
@@ -456,8 +455,8 @@ QPS_API int32_t qps_solve_batch(qps_handle hh, double* x, const qps_params* p, q
 QPS_API int32_t qps_set_profiling(qps_handle hh, int32_t on) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!h) return QPS_ERR_BAD_ARGUMENT;
-    if (h->impl) h->impl->prof.level = on;
-    for (auto* s : h->batch) s->prof.level = on;
+    if (h->impl) { h->impl->prof.level = on; h->impl->prof.reset(); }
+    for (auto* s : h->batch) { s->prof.level = on; s->prof.reset(); }
     return QPS_OK;
 }
 

@@ -184,12 +184,24 @@ def _sprandn_or_dense(rng, m, n, d, dense):
     return sprandn(rng, m, n, d)
 
 
-def GenerateDenseBenchmarkQP(numElements: int, numConstraints: int, *, seed: int = 1234, stream: int = 0):
+def GenerateDenseBenchmarkQP(numElements: int, numConstraints: int, *, seed: int = 1234, stream: int = 0,
+                             feasible: bool = False):
     """BASELINE.json dense configs: ``randomQp`` of GenerateQuadraticProgram.jl:10-16,27-35 at density
-    1.0, returned as dense column-major (Fortran-order) float64 arrays."""
+    1.0, returned as dense column-major (Fortran-order) float64 arrays.
+
+    With m = 2n the reference distribution is primal infeasible with overwhelming probability (15 % of the rows become
+    equalities pinned at their *upper* bound, :32-33, on top of 2n slabs around 0), so ADMM ends by the stall test
+    (convAdmm) and "time-to-eps" is undefined.  ``feasible=True`` keeps every draw but centres the bounds on A*x0 for a
+    random x0 and pins the equality rows at (A*x0)_i, which makes x0 feasible; it is used for time-to-eps only."""
     rng = make_rng(seed, stream)
     mP, vQ, mA, vL, vU = GenerateRandomQP(ProblemClass.randomQp, numElements, numConstraints=numConstraints, rng=rng,
                                           densityFctr=1.0, dense=True)
+    if feasible:
+        x0 = rng.standard_normal(numElements) / np.sqrt(numElements)
+        s = mA @ x0
+        eq = vL == vU
+        vL = np.where(eq, s, vL + s)
+        vU = np.where(eq, s, vU + s)
     return np.asfortranarray(mP), vQ, np.asfortranarray(mA), vL, vU
 
 

@@ -1,0 +1,95 @@
+"""CPU-only checks of the drop-in boundary: libqps_hip.so loads, exports every symbol include/qps.h declares, mirrors the
+reference defaults, validates arguments like SolveQuadraticProgram.m:158-184, and fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "qps.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qps_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(qps):
+    from quadraticprogramsolver_amd import _lib
+    names = header_functions()
+    assert names == sorted(_lib.EXPORTED_SYMBOLS)
+    L = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/qps.h but not exported"
+    assert b"gfx950" in _lib.lib().qps_version()
+
+
+def test_default_params_are_the_reference_defaults(qps):
+    """SolveQuadraticProgram.jl:15-17 and LinearSystemSolvers.jl:125."""
+    from quadraticprogramsolver_amd import _lib
+    p = _lib.default_params()
+    assert (p.numIterations, p.epsAbs, p.epsRel) == (5000, 1e-6, 1e-6)
+    assert (p.rho, p.sigma, p.alpha, p.delta, p.adptRho) == (1.0, 1e-6, 1.6, 1e-6, 0)
+    assert (p.fctrRho, p.numItrConv, p.numItrPolish, p.epsMinres, p.numItrMinres) == (5.0, 25, 10, 1e-6, 500)
+    assert (p.epsPcg, p.numItrPcg) == (1e-6, 1000)
+    assert C.sizeof(_lib.QpsParams) == 8 * 4 + 9 * 8 + 2 * 4
+    assert C.sizeof(_lib.QpsInfo) == 4 * 4 + 7 * 8
+
+
+def test_enums_match_reference(qps):
+    assert [int(f) for f in qps.ConvergenceFlag] == [1, 2, 3]          # SolveQuadraticProgram.jl:12
+    assert [f.name for f in qps.ConvergenceFlag] == ["convNumItr", "convAdmm", "convPrimDual"]
+    assert [f.name for f in qps.LinearSolverMode] == ["modeAuto", "modeItertaive", "modeDirect"]   # :11 (sic)
+    assert [int(c) for c in qps.ProblemClass] == list(range(1, 10))    # GenerateQuadraticProgram.jl:6
+
+
+def test_dimension_validation_mirrors_matlab_checks(qps):
+    P, q, A, l, u = np.eye(4), np.zeros(4), np.ones((3, 4)), -np.ones(3), np.ones(3)
+    with pytest.raises(ValueError):
+        qps.QuadraticProgram(np.ones((4, 3)), q, A, l, u)
+    with pytest.raises(ValueError):
+        qps.QuadraticProgram(P, np.zeros(5), A, l, u)
+    with pytest.raises(ValueError):
+        qps.QuadraticProgram(P, q, np.ones((3, 5)), l, u)
+    with pytest.raises(ValueError):
+        qps.QuadraticProgram(P, q, A, np.ones(2), u)
+    with pytest.raises(TypeError):   # an arbitrary CPU plugin pair is refused: there is no host loop in the product
+        qps.SolveQuadraticProgramInplace(np.zeros(4), P, q, A, l, u, lambda *a: None, lambda *a: None)
+
+
+def test_c_abi_status_codes_without_touching_the_gpu(qps):
+    from quadraticprogramsolver_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    dp = C.POINTER(C.c_double)
+    P = np.eye(3); q = np.zeros(3); A = np.ones((2, 3), order="F"); l = -np.ones(2); u = np.ones(2)
+    g = lambda a: a.ctypes.data_as(dp)
+    assert L.qps_create_dense(0, 2, g(P), 3, g(A), 2, g(q), g(l), g(u), 0, 0, C.byref(h)) == 2    # BAD_DIMENSION
+    assert L.qps_create_dense(3, 2, g(P), 2, g(A), 2, g(q), g(l), g(u), 0, 0, C.byref(h)) == 2    # ldp < n
+    assert L.qps_create_dense(3, 2, None, 3, g(A), 2, g(q), g(l), g(u), 0, 0, C.byref(h)) == 1    # BAD_ARGUMENT
+    assert L.qps_create_dense(3, 2, g(P), 3, g(A), 2, g(q), g(l), g(u), 7, 0, C.byref(h)) == 1    # unknown dtype
+    assert b"dtype" in L.qps_last_error(None)
+    assert L.qps_solve(None, g(q), None, None) == 1
+    assert L.qps_destroy(None) == 0
+
+
+def test_fails_loudly_without_a_gpu(qps):
+    from quadraticprogramsolver_amd import _lib
+    if _lib.lib().qps_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    P, q, A, l, u = np.eye(4), np.zeros(4), np.ones((3, 4)), -np.ones(3), np.ones(3)
+    with pytest.raises(qps.QpsError) as e:
+        qps.SolveQuadraticProgram(P, q, A, l, u)
+    assert e.value.status == 7 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may reference it."""
+    pkg = os.path.join(ROOT, "quadraticprogramsolver_amd")
+    for dp_, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dp_, f), errors="ignore").read()
+                assert "oracle" not in text.lower().replace("test infrastructure", ""), f"{f} mentions the oracle"

@@ -1,0 +1,226 @@
+"""GPU parity tests proper: every case calls libqps_hip.so through its C ABI and compares with the CPU oracle, the
+committed golden vectors, or a size-independent property.  Tolerances:
+  (i)   iterate level, fixed K, adptΡ off:        |x_gpu − x_ref|∞ ≤ 1e-9 · max(1, |x_ref|∞)      (fp64)
+  (ii)  solution level, RunTests.jl:50-58 params: |x_gpu − x_ref|∞ ≤ 1e-5 and the same ConvergenceFlag
+  (iii) KKT certificate recomputed on the host in fp64
+  fp32 (BASELINE config 5): 1e-3 relative at iterate level."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from quadraticprogramsolver_amd.generator import (GenerateDenseBenchmarkQP, GenerateRandomQP, ProblemClass, make_rng)
+
+pytestmark = pytest.mark.gpu
+ABS_DEV_THR = 1e-5   # RunTests.jl:58
+REF_KW = dict(numIterations=50000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True)   # RunTests.jl:50-54
+
+GOLDEN_PROBLEMS = ["c1_randomQp_n64_m128", "c1_randomQp_feasible_n64_m128", "c1_randomQp_n64_m32",
+                   "c1_equalityConstrainedQp_n64_m32", "c1_isotonicRegression_n64", "svm_n4_m40_infbounds"]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if b.size else 0.0
+
+
+@pytest.mark.parametrize("name", GOLDEN_PROBLEMS)
+def test_golden_iterates(gpu, name):
+    g = load_golden(name)
+    with gpu.QuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"]) as prob:
+        for K in (25, 50, 100):
+            x = np.zeros(g["P"].shape[0]); info = {}
+            flag = prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+            z, y = prob.dual()
+            assert flag == gpu.ConvergenceFlag.convNumItr and info["iterations"] == K
+            assert rel(x, g[f"x_K{K}"]) <= 1e-9 and rel(z, g[f"z_K{K}"]) <= 1e-9 and rel(y, g[f"y_K{K}"]) <= 1e-8
+
+
+@pytest.mark.parametrize("name", GOLDEN_PROBLEMS)
+def test_golden_solutions(gpu, name):
+    g = load_golden(name)
+    kw = dict(REF_KW)
+    if name == "c1_randomQp_n64_m128":
+        kw["numIterations"] = 200
+    x = np.zeros(g["P"].shape[0]); info = {}
+    flag = gpu.SolveQuadraticProgramInplace(x, g["P"], g["q"], g["A"], g["l"], g["u"], gpu.HipCholInit, gpu.HipChol, info=info, **kw)
+    assert int(flag) == int(g["flag"]) and info["iterations"] == int(g["iterations"]) and info["numRefactor"] == int(g["n_refactor"])
+    assert np.abs(x - g["x_final"]).max() <= ABS_DEV_THR
+
+
+@pytest.mark.parametrize("n", [4, 16, 64])
+@pytest.mark.parametrize("kat", ["unconstrained", "equality", "box_diag"])
+def test_known_answers(gpu, kat, n):
+    g = load_golden(f"kat_{kat}_n{n}")
+    x, flag = gpu.SolveQuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"], **REF_KW)
+    assert int(flag) in (2, 3)
+    assert np.abs(x - g["x_star"]).max() <= ABS_DEV_THR
+
+
+CASES = [(ProblemClass.randomQp, 100, 0, False), (ProblemClass.inequalityConstrainedQp, 100, 0, False),
+         (ProblemClass.equalityConstrainedQp, 100, 50, True), (ProblemClass.optimalControl, 100, 0, False),
+         (ProblemClass.portfolioOptimization, 100, 0, False), (ProblemClass.lassoOptimization, 10, 0, False),
+         (ProblemClass.huberFitting, 4, 0, False), (ProblemClass.supportVectorMachine, 10, 0, False),
+         (ProblemClass.isotonicRegression, 100, 0, False), (ProblemClass.randomQp, 300, 700, True),
+         (ProblemClass.randomQp, 1000, 500, True), (ProblemClass.randomQp, 1100, 2300, True)]
+
+
+@pytest.mark.parametrize("pc,n,m,dense", CASES)
+def test_iterates_match_oracle_all_classes(gpu, c_oracle, pc, n, m, dense):
+    """RunTests.jl:62-99 shape (every ProblemClass, sizes 10/100 and beyond) at iterate level against the C oracle."""
+    P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 40 + int(pc)), dense=dense,
+                                     densityFctr=1.0 if dense else None)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        for K, nb in ((25, 0), (100, 64), (50, 256)):
+            x = np.zeros(P.shape[0]); info = {}
+            prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, trsvBlock=nb, info=info)
+            z, y = prob.dual()
+            xo, io = c_oracle.solve(P, q, A, l, u, numIterations=K, epsAbs=0.0, epsRel=0.0, rho=0.1)
+            assert rel(x, xo) <= 1e-9 and rel(z, io["z"]) <= 1e-9 and rel(y, io["y"]) <= 1e-8
+            assert abs(info["resPrim"] - io["resPrim"]) <= 1e-9 * max(1.0, io["resPrim"])
+            assert abs(info["resDual"] - io["resDual"]) <= 1e-9 * max(1.0, io["resDual"])
+
+
+@pytest.mark.parametrize("pc,n,m,dense", CASES[:9])
+def test_solutions_match_oracle_and_kkt(gpu, c_oracle, np_oracle, pc, n, m, dense):
+    P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 60 + int(pc)), dense=dense,
+                                     densityFctr=1.0 if dense else None)
+    x = np.zeros(P.shape[0]); info = {}
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        flag = prob.solve(x, info=info, **REF_KW)
+        z, y = prob.dual()
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=50000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
+    assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+    assert np.abs(x - xo).max() <= ABS_DEV_THR
+    if int(flag) == 3:
+        prim, dual, comp = np_oracle.kkt_certificate(x, y, P, q, A, l, u)
+        assert prim <= 1e-5 * max(1.0, np.abs(z).max()) and dual <= 1e-4 and comp <= 1e-4
+
+
+def test_plugin_pair_drives_reference_loop(gpu, np_oracle):
+    """The literal plugin pair (LinearSystemSolvers.jl:16,28 signature) inside the oracle's reference-shaped loop:
+    CPU loop + GPU linear solve == CPU loop + CPU linear solve, including a changedΡ re-factorisation."""
+    g = load_golden("c1_randomQp_feasible_n64_m128")
+    xa = np.zeros(64); ia = {}
+    fa = np_oracle.SolveQuadraticProgramRefLoop(xa, g["P"], g["q"], g["A"], g["l"], g["u"], gpu.HipCholInit, gpu.HipChol,
+                                                numIterations=300, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True, info=ia)
+    xb = np.zeros(64); ib = {}
+    fb = np_oracle.SolveQuadraticProgramRefLoop(xb, g["P"], g["q"], g["A"], g["l"], g["u"], np_oracle.RedCholInit, np_oracle.RedChol,
+                                                numIterations=300, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True, info=ib)
+    assert fa == fb and ia["iterations"] == ib["iterations"] and ia["n_refactor"] == ib["n_refactor"] >= 1
+    assert rel(xa, xb) <= 1e-9
+
+
+def test_linear_solve_in_isolation(gpu, c_oracle):
+    rng = make_rng(11, 0)
+    n, m = 200, 333
+    M = rng.standard_normal((n, n)); P = M.T @ M + 1e-2 * np.eye(n); A = rng.standard_normal((m, n)); q = rng.standard_normal(n)
+    ref = c_oracle.LinSys(c_oracle.KIND_RED_CHOL, P, q, A, 0.3, 1e-6)
+    with gpu.QuadraticProgram(P, q, A, np.zeros(m), np.zeros(m)) as prob:
+        prob.linsys_init(0.3, 1e-6, trsvBlock=64)
+        for changed, rho in ((False, 0.3), (True, 40.0), (False, 40.0), (True, 1e-3)):
+            x, z, y = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(m)
+            xx, zz = np.zeros(n), np.zeros(m)
+            prob.linsys_solve(x, z, y, rho, 1e-6, changed, xx, zz)
+            xr, zr = ref.solve(x, z, y, rho, 1e-6, changed)
+            assert rel(xx, xr) <= 1e-9 and rel(zz, zr) <= 1e-9
+
+
+def test_edge_cases(gpu, c_oracle):
+    rng = make_rng(5, 5)
+    n = 8
+    M = rng.standard_normal((n, n)); P = M.T @ M + np.eye(n); q = rng.standard_normal(n)
+    # no constraints at all (empty A, l, u)
+    x, flag = gpu.SolveQuadraticProgram(P, q, np.zeros((0, n)), np.zeros(0), np.zeros(0), numIterations=5000, ϵAbs=1e-9, ϵRel=1e-9)
+    assert np.abs(x - np.linalg.solve(P, -q)).max() <= 1e-6
+    # n = 1
+    x, flag = gpu.SolveQuadraticProgram(np.array([[2.0]]), np.array([-4.0]), np.array([[1.0]]), np.array([-1.0]), np.array([1.0]), **REF_KW)
+    assert abs(x[0] - 1.0) <= ABS_DEV_THR
+    # warm start is honoured for x and z, y restart at 0 (SolveQuadraticProgram.jl:39-40)
+    g = load_golden("c1_randomQp_n64_m32")
+    x0 = make_rng(1, 2).standard_normal(64)
+    xg = x0.copy()
+    gpu.SolveQuadraticProgramInplace(xg, g["P"], g["q"], g["A"], g["l"], g["u"], numIterations=25, ϵAbs=0.0, ϵRel=0.0)
+    xo, _ = c_oracle.solve(g["P"], g["q"], g["A"], g["l"], g["u"], vX=x0, numIterations=25, epsAbs=0.0, epsRel=0.0)
+    assert rel(xg, xo) <= 1e-9
+    # numIterations not a multiple of numItrConv, numItrConv = 1
+    xg = np.zeros(64); info = {}
+    gpu.SolveQuadraticProgramInplace(xg, g["P"], g["q"], g["A"], g["l"], g["u"], numIterations=37, numItrConv=1, ϵAbs=1e-3, ϵRel=1e-3, info=info)
+    xo, io = c_oracle.solve(g["P"], g["q"], g["A"], g["l"], g["u"], numIterations=37, numItrConv=1, epsAbs=1e-3, epsRel=1e-3)
+    assert info["iterations"] == io["iterations"] and info["convFlag"] == io["convFlag"] and rel(xg, xo) <= 1e-9
+
+
+def test_error_behaviour(gpu):
+    # factorisation breakdown is reported, not hidden (reference: the library throws, LinearSystemSolvers.jl:18)
+    n = 70
+    P = -np.eye(n); A = np.zeros((1, n)); A[0, 0] = 1.0
+    with pytest.raises(gpu.QpsError) as e:
+        gpu.SolveQuadraticProgram(P, np.zeros(n), A, np.array([-1.0]), np.array([1.0]))
+    assert e.value.status == 4 and "pivot" in str(e.value)
+    with pytest.raises(gpu.QpsError) as e:
+        gpu.QuadraticProgram(np.full((3, 3), np.nan), np.zeros(3), np.zeros((1, 3)), np.zeros(1), np.zeros(1))
+    assert e.value.status == 3
+    with pytest.raises(gpu.QpsError):
+        gpu.SolveQuadraticProgram(np.eye(3), np.zeros(3), np.eye(3), -np.ones(3), np.ones(3), ρ=-1.0)
+
+
+def test_fp32_path(gpu, c_oracle):
+    """BASELINE config 5 arithmetic: fp32 loop + re-factorisation on every check (fctrΡ = 1, numItrConv = 50)."""
+    P, q, A, l, u = GenerateDenseBenchmarkQP(256, 512, stream=3, feasible=True)
+    x = np.zeros(256); info = {}
+    with gpu.QuadraticProgram(P, q, A, l, u, dtype="f32") as prob:
+        prob.solve(x, numIterations=50, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+        xo, io = c_oracle.solve(P, q, A, l, u, numIterations=50, epsAbs=0.0, epsRel=0.0, rho=0.1)
+        assert rel(x, xo) <= 1e-3
+        x = np.zeros(256)
+        flag = prob.solve(x, numIterations=2000, ϵAbs=1e-4, ϵRel=1e-4, ρ=0.1, adptΡ=True, fctrΡ=1.0, numItrConv=50, info=info)
+        xo, io = c_oracle.solve(P, q, A, l, u, numIterations=2000, epsAbs=1e-4, epsRel=1e-4, rho=0.1, adptRho=True, fctrRho=1.0, numItrConv=50)
+        assert info["numRefactor"] >= 1 and int(flag) in (2, 3)
+        assert np.abs(x - xo).max() <= 1e-2 * max(1.0, np.abs(xo).max())
+
+
+def test_batch_api(gpu, c_oracle):
+    cnt, n, m = 4, 96, 160
+    probs = [GenerateDenseBenchmarkQP(n, m, stream=10 + b, feasible=True) for b in range(cnt)]
+    import ctypes as C
+    from quadraticprogramsolver_amd import _lib
+    P = np.ascontiguousarray(np.stack([np.asfortranarray(p[0]).ravel(order="F") for p in probs]))
+    A = np.ascontiguousarray(np.stack([np.asfortranarray(p[2]).ravel(order="F") for p in probs]))
+    q = np.ascontiguousarray(np.stack([p[1] for p in probs])); l = np.ascontiguousarray(np.stack([p[3] for p in probs])); u = np.ascontiguousarray(np.stack([p[4] for p in probs]))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().qps_create_dense_batch(cnt, n, m, dp(P), dp(A), dp(q), dp(l), dp(u), 0, 0, C.byref(h)))
+    prm = _lib.default_params(); prm.numIterations = 100; prm.epsAbs = 0.0; prm.epsRel = 0.0; prm.rho = 0.1
+    X = np.zeros((cnt, n)); infos = (_lib.QpsInfo * cnt)()
+    _lib.check(_lib.lib().qps_solve_batch(h, dp(X), C.byref(prm), infos), h)
+    _lib.lib().qps_destroy(h)
+    for b in range(cnt):
+        xo, io = c_oracle.solve(*[probs[b][k] for k in (0, 1, 2, 3, 4)], numIterations=100, epsAbs=0.0, epsRel=0.0, rho=0.1)
+        assert rel(X[b], xo) <= 1e-9 and infos[b].iterations == 100
+
+
+def test_full_size_properties_c2(gpu):
+    """BASELINE config 2 (n = 4096, m = 8192, fp64) through size-independent properties: the linear solve satisfies
+    (P + σI + ρA'A) x~ = σx − q + A'(ρz − y) and z~ = A x~ to fp64 accuracy, the reported residuals are the true ones,
+    and every block size of the triangular sweep gives the same iterates."""
+    n, m = 4096, 8192
+    P, q, A, l, u = GenerateDenseBenchmarkQP(n, m)
+    rng = make_rng(77, 0)
+    rho, sigma = 0.1, 1e-6
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        prob.linsys_init(rho, sigma, trsvBlock=2048)
+        x, z, y = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(m)
+        xx, zz = np.zeros(n), np.zeros(m)
+        prob.linsys_solve(x, z, y, rho, sigma, False, xx, zz)
+        rhs = sigma * x - q + A.T @ (rho * z - y)
+        lhs = P @ xx + sigma * xx + rho * (A.T @ (A @ xx))
+        assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(rhs).max()
+        assert np.abs(zz - A @ xx).max() <= 1e-11 * max(1.0, np.abs(zz).max())
+        xs = []
+        for nb in (512, 2048, 4096):
+            xk = np.zeros(n); info = {}
+            prob.solve(xk, numIterations=50, ϵAbs=0.0, ϵRel=0.0, ρ=rho, trsvBlock=nb, info=info)
+            xs.append(xk)
+            zk, yk = prob.dual()
+            assert abs(info["resPrim"] - np.abs(A @ xk - zk).max()) <= 1e-9 * max(1.0, info["resPrim"])
+            assert abs(info["resDual"] - np.abs(P @ xk + q + A.T @ yk).max()) <= 1e-8 * max(1.0, info["resDual"])
+            assert np.all(zk >= l - 1e-12) and np.all(zk <= u + 1e-12)
+        assert rel(xs[0], xs[1]) <= 1e-9 and rel(xs[2], xs[1]) <= 1e-9
