@@ -64,7 +64,8 @@ typedef struct {
     int32_t numItrPolish;    /* 10 (ignored) */
     int32_t numItrMinres;    /* 500 (ignored) */
     int32_t linsys;          /* qps_linsys_kind, additive, default AUTO */
-    int32_t trsvBlock;       /* additive: diagonal-block size of the blocked triangular sweep (0 = library default)   */
+    int32_t trsvBlock;       /* additive: size of the inverted diagonal blocks of the blocked triangular sweep; a
+                                power-of-two multiple of 64, 0 = library default min(4096, n padded)                  */
     int32_t reuseFactor;     /* additive: 1 = keep the factorisation of a previous qps_solve/linsys_init when
                                 (rho, sigma) are unchanged; 0 = factorise on every call like the reference (:36)      */
     double epsAbs;           /* ϵAbs 1e-6 */
@@ -77,7 +78,8 @@ typedef struct {
     double epsMinres;        /* ϵMinres 1e-6 (ignored) */
     double epsPcg;           /* CG plugins' ϵPcg 1e-6 (LinearSystemSolvers.jl:125) */
     int32_t numItrPcg;       /* CG plugins' numItrPcg 1000 */
-    int32_t reserved;
+    int32_t loopVariant;     /* additive: 0 = fused single pass over A per iteration when the shape allows (default),
+                                1 = unfused kernels (A read twice; the literal order of LinearSystemSolvers.jl:134-139) */
 } qps_params;
 
 /* Additive out-of-band report (the reference returns only the flag, SolveQuadraticProgram.jl:73). */

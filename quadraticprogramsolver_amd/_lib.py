@@ -48,7 +48,7 @@ class QpsParams(C.Structure):
                 ("trsvBlock", C.c_int32), ("reuseFactor", C.c_int32),
                 ("epsAbs", C.c_double), ("epsRel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
                 ("alpha", C.c_double), ("delta", C.c_double), ("fctrRho", C.c_double), ("epsMinres", C.c_double),
-                ("epsPcg", C.c_double), ("numItrPcg", C.c_int32), ("reserved", C.c_int32)]
+                ("epsPcg", C.c_double), ("numItrPcg", C.c_int32), ("loopVariant", C.c_int32)]
 
 
 class QpsInfo(C.Structure):

@@ -24,13 +24,13 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // Row-dot GEMV: one workgroup (256 threads) owns RB rows and walks their columns in chunks of 256 lanes x 16 B.
 // Used for: z~ = A x~ (LinearSystemSolvers.jl:139), both triangular sweeps over S, P x / A x in CheckConvergence.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int RB, int TRI>
-__global__ __launch_bounds__(256) void k_gemv_rows(const T* __restrict__ S, int64_t ld, const T* __restrict__ v,
+template <typename T, int RB, int TRI, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gemv_rows(const T* __restrict__ S, int64_t ld, const T* __restrict__ v,
                                                    T* __restrict__ out, const T* __restrict__ out0, T alpha, T beta,
                                                    int r0, int c0, int c1) {
     using V = typename VecOf<T>::type;
     constexpr int VN = VecOf<T>::N;
-    constexpr int CHUNK = 256 * VN;
+    constexpr int CHUNK = THREADS * VN;
     const int tid = threadIdx.x;
     const int rb = r0 + blockIdx.x * RB;
     int cb = c0, ce = c1;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const T* __restrict__ S, int6
             }
         }
     }
-    __shared__ T red[4][RB];
+    __shared__ T red[THREADS / 64][RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) acc[i] = wave_sum(acc[i]);
     if ((tid & 63) == 0) {
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const T* __restrict__ S, int6
     }
     __syncthreads();
     if (tid < RB) {
-        T s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        T s = T(0);
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) s += red[w][tid];   // fixed order -> bitwise reproducible
         T r = alpha * s;
         if (beta != T(0)) r += beta * out0[rb + tid];
         out[rb + tid] = r;
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const T* __restrict__ S, int6
     *reinterpret_cast<V*>(part + (int64_t)rt * part_ld + c) = o;
 }
 
-// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  Workgroup = 16 columns x 16 tile lanes: each 128-B line of a
-// slab row is read by 16 lanes, 16 slab rows per workgroup-iteration.
+// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  Workgroup = 16 columns x 16 slab lanes: each 128-B line of a
+// slab row is read by 16 lanes, 16 slab rows per workgroup-iteration, 8 loads in flight per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int64_t part_ld, int ntiles,
                                                 const T* __restrict__ a0, T s0, const T* __restrict__ a1, T s1,
@@ -118,8 +120,17 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int6
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     T acc = T(0);
-    if (c < ncols)
-        for (int t = tl; t < ntiles; t += 16) acc += part[(int64_t)t * part_ld + c];
+    if (c < ncols) {
+        int t = tl;
+        for (; t + 112 < ntiles; t += 128) {
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(t + 16 * j) * part_ld + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; t < ntiles; t += 16) acc += part[(int64_t)t * part_ld + c];
+    }
     __shared__ T red[16][17];
     red[tl][cl] = acc;
     __syncthreads();
@@ -167,12 +178,12 @@ __global__ __launch_bounds__(256) void k_check_norms(int n, int m, const T* __re
                                                      const T* __restrict__ Aty, const T* __restrict__ q,
                                                      const T* __restrict__ x, const T* __restrict__ xp,
                                                      const T* __restrict__ z, const T* __restrict__ zp,
-                                                     unsigned long long* __restrict__ slots) {
+                                                     unsigned long long* __restrict__ slots, int dual_only) {
     unsigned long long v[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = 0ull;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < max(n, m); i += gridDim.x * 256) {
-        if (i < m) {
+        if (i < m && !dual_only) {
             const double ax = (double)Ax[i], zi = (double)z[i];
             // differences are formed in T to match a T-precision reference of norm(mA * vX - vZ, Inf)
             v[0] = max(v[0], absbits((double)(Ax[i] - z[i])));
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256) void k_check_norms(int n, int m, const T* __re
             v[4] = max(v[4], absbits((double)Px[i]));
             v[5] = max(v[5], absbits((double)Aty[i]));
             v[6] = max(v[6], absbits((double)q[i]));
-            v[7] = max(v[7], absbits((double)(x[i] - xp[i])));
+            if (!dual_only) v[7] = max(v[7], absbits((double)(x[i] - xp[i])));
         }
     }
 #pragma unroll
@@ -242,10 +253,14 @@ void gemv_rows(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const
                int c0, int c1, int tri) {
     constexpr int RB = 4;
     if (r1 <= r0) return;
-    dim3 grid((r1 - r0 + RB - 1) / RB), block(256);
-    if (tri == 0) hipLaunchKernelGGL((k_gemv_rows<T, RB, 0>), grid, block, 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1);
-    else if (tri == 1) hipLaunchKernelGGL((k_gemv_rows<T, RB, 1>), grid, block, 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1);
-    else hipLaunchKernelGGL((k_gemv_rows<T, RB, 2>), grid, block, 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1);
+    dim3 grid((r1 - r0 + RB - 1) / RB);
+    // wide rows: 1024 threads cover 2048 (fp64) / 4096 (fp32) columns per step, so a 4096-column row needs two loads per
+    // thread per row, all in flight at once (one memory round trip per workgroup instead of eight)
+    const bool wide = (c1 - c0) >= 4 * 256 * VecOf<T>::N;
+#define QPS_GR(TRI, TH) hipLaunchKernelGGL((k_gemv_rows<T, RB, TRI, TH>), grid, dim3(TH), 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1)
+    if (wide) { if (tri == 0) QPS_GR(0, 1024); else if (tri == 1) QPS_GR(1, 1024); else QPS_GR(2, 1024); }
+    else      { if (tri == 0) QPS_GR(0, 256);  else if (tri == 1) QPS_GR(1, 256);  else QPS_GR(2, 256); }
+#undef QPS_GR
 }
 
 int gemv_cols_tiles(int nrows) { return (nrows + GC_RT - 1) / GC_RT; }
@@ -276,13 +291,14 @@ void admm_update(hipStream_t st, int NP, int MP, const T* xx, const T* zz, T* x,
 
 template <typename T>
 void check_convergence(hipStream_t st, int n, int m, const T* Ax, const T* Px, const T* Aty, const T* q, const T* x,
-                       const T* xp, const T* z, const T* zp, unsigned long long* scratch, double* res_dev, CheckScalars cs) {
-    (void)hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long), st);
+                       const T* xp, const T* z, const T* zp, unsigned long long* scratch, double* res_dev, CheckScalars cs,
+                       int dual_only) {
+    if (!dual_only) (void)hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long), st);
     const int N = n > m ? n : m;
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_check_norms<T>), dim3(blocks), dim3(256), 0, st, n, m, Ax, Px, Aty, q, x, xp, z, zp, scratch);
+    hipLaunchKernelGGL((k_check_norms<T>), dim3(blocks), dim3(256), 0, st, n, m, Ax, Px, Aty, q, x, xp, z, zp, scratch, dual_only);
     hipLaunchKernelGGL(k_check_decide, dim3(1), dim3(64), 0, st, scratch, res_dev, cs);
 }
 
@@ -305,7 +321,7 @@ template <typename T> void convert_back(hipStream_t st, const T* src, double* ds
     template void colsum<T>(hipStream_t, const T*, int64_t, int, const T*, T, const T*, T, T*, int);                         \
     template void admm_update<T>(hipStream_t, int, int, const T*, const T*, T*, T*, T*, T*, T*, const T*, const T*, T, T);   \
     template void check_convergence<T>(hipStream_t, int, int, const T*, const T*, const T*, const T*, const T*, const T*,    \
-                                       const T*, const T*, unsigned long long*, double*, CheckScalars);                      \
+                                       const T*, const T*, unsigned long long*, double*, CheckScalars, int);                      \
     template void fill<T>(hipStream_t, T*, int64_t, T);                                                                      \
     template void convert_copy<T>(hipStream_t, const double*, T*, int64_t);                                                  \
     template void convert_back<T>(hipStream_t, const T*, double*, int64_t);

@@ -13,7 +13,7 @@ namespace {
 thread_local std::string g_last_error;
 
 int pick_nb(int requested, int NP) {
-    int nb = requested > 0 ? requested : 2048;
+    int nb = requested > 0 ? requested : 4096;
     int p = 64; while (p * 2 <= nb) p *= 2;   // power-of-two multiple of 64
     nb = p;
     while (nb > 64 && nb / 2 >= NP) nb /= 2;
@@ -28,11 +28,12 @@ template <typename T> struct DenseSolver : SolverBase {
     T *A = nullptr, *P = nullptr, *q = nullptr, *l = nullptr, *u = nullptr;
     T *PI = nullptr, *AA = nullptr, *M = nullptr, *S = nullptr, *tmp = nullptr, *dinv = nullptr; int* fail = nullptr;
     T *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr, *xx = nullptr, *zz = nullptr, *tt = nullptr, *yv = nullptr;
-    T *part = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
+    T *part = nullptr, *part2 = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
+    int pass_slabs = 0, pass_rpw = 0;   // fused-pass plan (0 slabs: shape not supported, unfused loop only)
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
     int nb = 2048; int part_tiles = 0;
-    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk;
+    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk;
 
     DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
         device = dev; n = n_; m = m_; dtype = dt;
@@ -47,7 +48,10 @@ template <typename T> struct DenseSolver : SolverBase {
         x = dalloc<T>(NP); xp = dalloc<T>(NP); xx = dalloc<T>(NP); tt = dalloc<T>(NP); yv = dalloc<T>(NP);
         z = dalloc<T>(MP); zp = dalloc<T>(MP); y = dalloc<T>(MP); zz = dalloc<T>(MP);
         part_tiles = gemv_cols_tiles(MP);
-        part = dalloc<T>((int64_t)(part_tiles > 0 ? part_tiles : 1) * NP);
+        pass_slabs = apass_plan<T>(NP, MP, &pass_rpw);
+        const int slabs = std::max(std::max(part_tiles, pass_slabs), 1);
+        part = dalloc<T>((int64_t)slabs * NP);
+        part2 = dalloc<T>((int64_t)slabs * NP);
         Ax = dalloc<T>(MP); Px = dalloc<T>(NP); Aty = dalloc<T>(NP);
         scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
         HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
@@ -61,11 +65,14 @@ template <typename T> struct DenseSolver : SolverBase {
         cat_ax = prof.category("gemv_rows(Ax~)", s * ((double)m * n + m + n));
         cat_upd = prof.category("admm_update", s * (3.0 * n + 7.0 * m));
         cat_chk = prof.category("check_convergence", s * (2.0 * m * n + (double)n * n + 4.0 * n + 4.0 * m));
+        // fused pass: A once + x~, x, z, y, l, u in, x, z, y out (s*m*n + vector traffic)
+        cat_pass = prof.category("apass(fused A-pass)", s * ((double)m * n + 3.0 * n + 6.0 * m));
+        cat_passchk = prof.category("apass(check variant)", s * ((double)m * n + 4.0 * n + 6.0 * m));
     }
     ~DenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
-        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, Ax, Px, Aty, scratch, res_dev, stage};
+        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, Ax, Px, Aty, scratch, res_dev, stage};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (res_host) (void)hipHostFree(res_host);
         if (st) (void)hipStreamDestroy(st);
@@ -178,20 +185,24 @@ template <typename T> struct DenseSolver : SolverBase {
         const double t1 = now_s();
         double rhorho = rho;                                                                        // :43
         int ii = 0, nref = 0; double tref = 0, resP = NAN, resD = NAN;
+        const bool fused = pass_slabs > 0 && p.loopVariant != 1;
+        int rhs_slabs = 0;   // z = y = 0: A'(rho z - y) = 0, no slab to add for the first right-hand side
         for (ii = 1; ii <= p.numIterations; ++ii) {                                                 // :45
+            bool changed = false;
             if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {          // :47
-                rho = rhorho; ++nref;                                                               // :48-51
+                rho = rhorho; ++nref; changed = true;                                               // :48-51
                 const double ta = now_s();
                 factorize(rho, sigma, false);                                                       // changedΡ: LinearSystemSolvers.jl:127-129
                 tref += now_s() - ta;
             }
-            linear_solve(rho, sigma);                                                               // :54
-            {
-                ProfScope ps(prof, cat_upd, 2);
-                admm_update<T>(st, NP, MP, xx, zz, x, xp, z, zp, y, l, u, (T)alpha, (T)rho);         // :56-61
-            }
-            if (ii % p.numItrConv == 0) {                                                           // :63
+            const bool check = (ii % p.numItrConv == 0);                                            // :63
+            if (!fused) {
+                linear_solve(rho, sigma);                                                           // :54
                 {
+                    ProfScope ps(prof, cat_upd, 2);
+                    admm_update<T>(st, NP, MP, xx, zz, x, xp, z, zp, y, l, u, (T)alpha, (T)rho);     // :56-61
+                }
+                if (check) {
                     ProfScope ps(prof, cat_chk, 2);
                     gemv_rows<T>(st, A, NP, x, Ax, nullptr, T(1), T(0), 0, MP, 0, NP, 0);            // mA * vX
                     gemv_rows<T>(st, P, NP, x, Px, nullptr, T(1), T(0), 0, NP, 0, NP, 0);            // mP * vX
@@ -200,6 +211,34 @@ template <typename T> struct DenseSolver : SolverBase {
                     CheckScalars cs{p.epsAbs, p.epsRel, epsAdmm, rho, rhorho, p.adptRho, convFlag};
                     check_convergence<T>(st, (int)n, (int)m, Ax, Px, Aty, q, x, xp, z, zp, scratch, res_dev, cs);   // :64
                 }
+            } else {
+                // Fused loop: the pass of iteration ii-1 already left the slabs of A'(rho z - y); after a rho switch they
+                // are stale (w depends on rho) and are rebuilt by the plain column GEMV.
+                if (changed && rhs_slabs > 0) {
+                    ProfScope ps(prof, cat_atw, 2);
+                    rhs_slabs = gemv_cols_partial<T>(st, A, NP, z, y, (T)rho, T(-1), part, NP, MP, NP);
+                }
+                {
+                    ProfScope ps(prof, cat_colsum, 2);
+                    colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP);              // LinearSystemSolvers.jl:136
+                }
+                sweeps();                                                                           // :137
+                if (check) HIPC(hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long), st));
+                {
+                    ProfScope ps(prof, check ? cat_passchk : cat_pass, 1);
+                    apass<T>(st, check, A, NP, NP, MP, xx, x, xp, z, y, l, u, (T)alpha, (T)rho, part, part2, NP, scratch);
+                }
+                std::swap(x, xp);   // x now holds the relaxed iterate, xp the previous one (SolveQuadraticProgram.jl:56-57)
+                rhs_slabs = pass_slabs;
+                if (check) {
+                    ProfScope ps(prof, cat_chk, 2);
+                    colsum<T>(st, part2, NP, pass_slabs, nullptr, T(0), nullptr, T(0), Aty, NP);     // mA' * vY
+                    gemv_rows<T>(st, P, NP, x, Px, nullptr, T(1), T(0), 0, NP, 0, NP, 0);            // mP * vX
+                    CheckScalars cs{p.epsAbs, p.epsRel, epsAdmm, rho, rhorho, p.adptRho, convFlag};
+                    check_convergence<T>(st, (int)n, (int)m, Ax, Px, Aty, q, x, xp, z, zp, scratch, res_dev, cs, 1);
+                }
+            }
+            if (check) {
                 HIPC(hipMemcpyAsync(res_host, res_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPC(hipStreamSynchronize(st));
                 prof.harvest();
@@ -315,7 +354,7 @@ QPS_API int32_t qps_default_params(qps_params* p) {
     p->numIterations = 5000; p->epsAbs = 1e-6; p->epsRel = 1e-6;            // SolveQuadraticProgram.jl:15
     p->rho = 1.0; p->sigma = 1e-6; p->alpha = 1.6; p->delta = 1e-6; p->adptRho = 0;   // :16
     p->fctrRho = 5.0; p->numItrConv = 25; p->numItrPolish = 10; p->epsMinres = 1e-6; p->numItrMinres = 500;   // :17
-    p->linsys = QPS_LINSYS_AUTO; p->trsvBlock = 0; p->reuseFactor = 0;
+    p->linsys = QPS_LINSYS_AUTO; p->trsvBlock = 0; p->reuseFactor = 0; p->loopVariant = 0;
     p->epsPcg = 1e-6; p->numItrPcg = 1000;                                  // LinearSystemSolvers.jl:125
     return QPS_OK;
 }

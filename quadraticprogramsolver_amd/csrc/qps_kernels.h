@@ -45,7 +45,18 @@ struct CheckScalars { double epsAbs, epsRel, epsAdmm, rho, rhorho; int adptRho; 
 template <typename T>
 void check_convergence(hipStream_t st, int n, int m, const T* Ax, const T* Px, const T* Aty, const T* q, const T* x,
                        const T* xp, const T* z, const T* zp, unsigned long long* scratch /*>=16 u64*/, double* res_dev,
-                       CheckScalars cs);
+                       CheckScalars cs, int dual_only = 0);
+// dual_only = 1: the primal-side slots (0,2,3,7,8) were already filled by the fused pass (k_pass.hip); scratch is not
+// cleared and only the n-length norms are added before the decision.
+
+// ---- fused single pass over A (k_pass.hip) -----------------------------------------------------------------------
+// z~ = A x~, z/y update (SolveQuadraticProgram.jl:59-61), x_new = alpha x~ + (1-alpha) x_old (:57), slabs of
+// A'(rho z_new - y_new) for the next right-hand side; check = true adds A x_new norms, slabs of A'y_new, |x_new-x_old|.
+template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg);   // number of slabs (0: shape not supported)
+template <typename T> int apass_max_np();
+template <typename T>
+void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
+           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots);
 
 template <typename T> void fill(hipStream_t st, T* p, int64_t n, T v);
 template <typename T> void convert_copy(hipStream_t st, const double* src, T* dst, int64_t n);   // dst[i] = (T)src[i]

@@ -105,7 +105,7 @@ class QuadraticProgram:
     # -- SolveQuadraticProgram! -----------------------------------------------------------------------------------
     def solve(self, vX, *, numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=False, fctrΡ=5,
               numItrConv=25, numItrPolish=10, ϵMinres=1e-6, numItrMinres=500, ϵPcg=1e-6, numItrPcg=1000,
-              trsvBlock=0, reuseFactor=False, info=None):
+              trsvBlock=0, reuseFactor=False, loopVariant=0, info=None):
         """Mutates ``vX`` (warm start in, solution out) and returns the ConvergenceFlag."""
         if not isinstance(vX, np.ndarray) or vX.dtype != np.float64 or not vX.flags.c_contiguous or vX.shape != (self.n,):
             raise ValueError("vX must be a contiguous float64 vector of length numElements (it is updated in place)")
@@ -116,6 +116,7 @@ class QuadraticProgram:
         p.numItrPolish, p.epsMinres, p.numItrMinres = int(numItrPolish), float(ϵMinres), int(numItrMinres)
         p.epsPcg, p.numItrPcg = float(ϵPcg), int(numItrPcg)
         p.linsys, p.trsvBlock, p.reuseFactor = self.linsys, int(trsvBlock), int(bool(reuseFactor))
+        p.loopVariant = int(loopVariant)
         inf = QpsInfo()
         _lib.check(_lib.lib().qps_solve(self._h, _dp(vX), C.byref(p), C.byref(inf)), self._h)
         if info is not None:

@@ -69,9 +69,9 @@ def test_iterates_match_oracle_all_classes(gpu, c_oracle, pc, n, m, dense):
     P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 40 + int(pc)), dense=dense,
                                      densityFctr=1.0 if dense else None)
     with gpu.QuadraticProgram(P, q, A, l, u) as prob:
-        for K, nb in ((25, 0), (100, 64), (50, 256)):
+        for K, nb, variant in ((25, 0, 0), (100, 64, 0), (50, 256, 1), (75, 0, 0)):   # variant 1 = unfused kernels
             x = np.zeros(P.shape[0]); info = {}
-            prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, trsvBlock=nb, info=info)
+            prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, trsvBlock=nb, loopVariant=variant, info=info)
             z, y = prob.dual()
             xo, io = c_oracle.solve(P, q, A, l, u, numIterations=K, epsAbs=0.0, epsRel=0.0, rho=0.1)
             assert rel(x, xo) <= 1e-9 and rel(z, io["z"]) <= 1e-9 and rel(y, io["y"]) <= 1e-8
@@ -93,6 +93,22 @@ def test_solutions_match_oracle_and_kkt(gpu, c_oracle, np_oracle, pc, n, m, dens
     if int(flag) == 3:
         prim, dual, comp = np_oracle.kkt_certificate(x, y, P, q, A, l, u)
         assert prim <= 1e-5 * max(1.0, np.abs(z).max()) and dual <= 1e-4 and comp <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["c1_randomQp_feasible_n64_m128", "c1_isotonicRegression_n64"])
+def test_fused_and_unfused_loops_agree(gpu, name):
+    """The fused single-pass loop and the literal LinearSystemSolvers.jl:134-139 kernel order give the same run,
+    including the rho switches (the slabs of A'(rho z - y) are rebuilt on changedΡ)."""
+    g = load_golden(name)
+    out = []
+    with gpu.QuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"]) as prob:
+        for variant in (0, 1):
+            x = np.zeros(g["P"].shape[0]); info = {}
+            flag = prob.solve(x, loopVariant=variant, info=info, **REF_KW)
+            out.append((x, int(flag), info["iterations"], info["numRefactor"], info["resPrim"], info["resDual"]))
+    assert out[0][1:4] == out[1][1:4] == (int(g["flag"]), int(g["iterations"]), int(g["n_refactor"]))
+    assert rel(out[0][0], out[1][0]) <= 1e-9
+    assert abs(out[0][4] - out[1][4]) <= 1e-9 * max(1.0, out[1][4]) and abs(out[0][5] - out[1][5]) <= 1e-9 * max(1.0, out[1][5])
 
 
 def test_plugin_pair_drives_reference_loop(gpu, np_oracle):
@@ -215,9 +231,9 @@ def test_full_size_properties_c2(gpu):
         assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(rhs).max()
         assert np.abs(zz - A @ xx).max() <= 1e-11 * max(1.0, np.abs(zz).max())
         xs = []
-        for nb in (512, 2048, 4096):
+        for nb, variant in ((512, 0), (2048, 1), (4096, 0)):
             xk = np.zeros(n); info = {}
-            prob.solve(xk, numIterations=50, ϵAbs=0.0, ϵRel=0.0, ρ=rho, trsvBlock=nb, info=info)
+            prob.solve(xk, numIterations=50, ϵAbs=0.0, ϵRel=0.0, ρ=rho, trsvBlock=nb, loopVariant=variant, info=info)
             xs.append(xk)
             zk, yk = prob.dual()
             assert abs(info["resPrim"] - np.abs(A @ xk - zk).max()) <= 1e-9 * max(1.0, info["resPrim"])

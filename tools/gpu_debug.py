@@ -40,14 +40,14 @@ if __name__ == "__main__":
         n, m = 4096, 8192
         t = time.time(); P, qq, A, l, u = q.GenerateDenseBenchmarkQP(n, m); print("gen", time.time() - t, flush=True)
         t = time.time(); prob = q.QuadraticProgram(P, qq, A, l, u); print("create", time.time() - t, flush=True)
-        for nb in (512, 1024, 2048, 4096):
+        for nb, variant in ((4096, 1), (1024, 0), (2048, 0), (4096, 0)):
             x = np.zeros(n); info = {}
             prob.set_profiling(0)
-            prob.solve(x, numIterations=200, ϵAbs=0.0, ϵRel=0.0, trsvBlock=nb, info=info)
-            print(f"nb={nb} setup {info['tSetup']*1e3:.1f} ms loop {info['tLoop']*1e3:.1f} ms -> {info['iterations']/info['tLoop']:.1f} it/s", flush=True)
+            prob.solve(x, numIterations=200, ϵAbs=0.0, ϵRel=0.0, trsvBlock=nb, loopVariant=variant, info=info)
+            print(f"nb={nb} variant={variant} setup {info['tSetup']*1e3:.1f} ms loop {info['tLoop']*1e3:.1f} ms -> {info['iterations']/info['tLoop']:.1f} it/s", flush=True)
             prob.set_profiling(2)
             x2 = np.zeros(n)
-            prob.solve(x2, numIterations=100, ϵAbs=0.0, ϵRel=0.0, trsvBlock=nb, reuseFactor=True, info=info)
+            prob.solve(x2, numIterations=100, ϵAbs=0.0, ϵRel=0.0, trsvBlock=nb, reuseFactor=True, loopVariant=variant, info=info)
             for k in prob.kernel_times():
                 us = k['seconds'] / k['launches'] * 1e6
                 print(f"   {k['name']:24s} {us:9.1f} us/launch  {k['algo_bytes']/us/1e6:8.3f} TB/s algorithmic  ({k['launches']} launches)")
