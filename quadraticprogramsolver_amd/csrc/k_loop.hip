@@ -1,5 +1,7 @@
 // k_loop.hip -- per-iteration kernels of the device-resident ADMM loop (gfx950 / CDNA4, wave64).
 // All of them are HBM-bound (<= 0.25 flop/byte): 16-byte-per-lane coalesced loads, wave64 shuffle reductions, no MFMA.
+#include <cstdlib>
+
 #include "qps_kernels.h"
 
 namespace qps {
@@ -32,7 +34,8 @@ __global__ __launch_bounds__(THREADS) void k_gemv_rows(const T* __restrict__ S, 
     constexpr int VN = VecOf<T>::N;
     constexpr int CHUNK = THREADS * VN;
     const int tid = threadIdx.x;
-    const int rb = r0 + blockIdx.x * RB;
+    // lower-triangular rows get longer with r: dispatch the long ones first so the tail of the launch is made of short rows
+    const int rb = r0 + (TRI == 1 ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * RB;
     int cb = c0, ce = c1;
     if (TRI == 1) ce = min(c1, rb + RB);
     if (TRI == 2) cb = max(c0, rb);
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(THREADS) void k_gemv_rows(const T* __restrict__ S, 
 #pragma unroll
     for (int i = 0; i < RB; ++i) acc[i] = T(0);
     const T* Srow = S + (int64_t)rb * ld;
-#pragma unroll 2
+#pragma unroll 4
     for (int c = cb + tid * VN; c < ce; c += CHUNK) {
         const V vv = *reinterpret_cast<const V*>(v + c);
         const T* vp = reinterpret_cast<const T*>(&vv);
@@ -111,37 +114,54 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const T* __restrict__ S, int6
     *reinterpret_cast<V*>(part + (int64_t)rt * part_ld + c) = o;
 }
 
-// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  Workgroup = 16 columns x 16 slab lanes: each 128-B line of a
-// slab row is read by 16 lanes, 16 slab rows per workgroup-iteration, 8 loads in flight per thread.
+// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  A workgroup owns 16 consecutive columns (one 128-B line per slab
+// row for fp64); CL lanes cover the line with 16-B loads and the other 256/CL lane groups walk the slabs, 8 loads in
+// flight per thread, so 256 slabs are consumed in one memory round trip.
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int64_t part_ld, int ntiles,
                                                 const T* __restrict__ a0, T s0, const T* __restrict__ a1, T s1,
                                                 T* __restrict__ out, int ncols) {
-    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    T acc = T(0);
+    using V = typename VecOf<T>::type;
+    constexpr int VN = VecOf<T>::N;
+    constexpr int CL = 16 / VN;          // lanes per 16-column group
+    constexpr int TL = 256 / CL;         // slab lanes
+    const int cl = threadIdx.x % CL, tl = threadIdx.x / CL;
+    const int c = blockIdx.x * 16 + cl * VN;
+    T acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = T(0);
     if (c < ncols) {
         int t = tl;
-        for (; t + 112 < ntiles; t += 128) {
-            T v[8];
+        for (; t + 7 * TL < ntiles; t += 8 * TL) {
+            V v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(t + 16 * j) * part_ld + c];
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const V*>(part + (int64_t)(t + TL * j) * part_ld + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += v[j];
+            for (int j = 0; j < 8; ++j) {
+                const T* vp = reinterpret_cast<const T*>(&v[j]);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] += vp[e];
+            }
         }
-        for (; t < ntiles; t += 16) acc += part[(int64_t)t * part_ld + c];
-    }
-    __shared__ T red[16][17];
-    red[tl][cl] = acc;
-    __syncthreads();
-    if (threadIdx.x < 16 && c < ncols) {
-        T s = T(0);
+        for (; t < ntiles; t += TL) {
+            const V v = *reinterpret_cast<const V*>(part + (int64_t)t * part_ld + c);
+            const T* vp = reinterpret_cast<const T*>(&v);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) s += red[t][threadIdx.x];   // fixed order -> bitwise reproducible
+            for (int e = 0; e < VN; ++e) acc[e] += vp[e];
+        }
+    }
+    __shared__ T red[TL][17];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) red[tl][cl * VN + e] = acc[e];
+    __syncthreads();
+    const int oc = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && oc < ncols) {
+        T s = T(0);
+        for (int t = 0; t < TL; ++t) s += red[t][threadIdx.x];   // fixed order -> bitwise reproducible
         T r = s;
-        if (a0) r += s0 * a0[c];
-        if (a1) r += s1 * a1[c];
-        out[c] = r;
+        if (a0) r += s0 * a0[oc];
+        if (a1) r += s1 * a1[oc];
+        out[oc] = r;
     }
 }
 
@@ -248,19 +268,32 @@ template <typename T> __global__ void k_convert_back(const T* __restrict__ s, do
 
 }  // namespace
 
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+template <typename T, int RB, int TH>
+static void gemv_rows_launch(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta, int r0,
+                             int r1, int c0, int c1, int tri) {
+    dim3 grid((r1 - r0 + RB - 1) / RB);
+#define QPS_GR(TRI) hipLaunchKernelGGL((k_gemv_rows<T, RB, TRI, TH>), grid, dim3(TH), 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1)
+    if (tri == 0) QPS_GR(0); else if (tri == 1) QPS_GR(1); else QPS_GR(2);
+#undef QPS_GR
+}
+
 template <typename T>
 void gemv_rows(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta, int r0, int r1,
                int c0, int c1, int tri) {
-    constexpr int RB = 4;
     if (r1 <= r0) return;
-    dim3 grid((r1 - r0 + RB - 1) / RB);
-    // wide rows: 1024 threads cover 2048 (fp64) / 4096 (fp32) columns per step, so a 4096-column row needs two loads per
-    // thread per row, all in flight at once (one memory round trip per workgroup instead of eight)
+    // wide rows: more threads per row block so that every load of the block is in flight at once
+    static const int wide_th = env_int("QPS_GEMV_WIDE_THREADS", 512);   // measured best on C2: 512 threads x 2 rows
+    static const int wide_rb = env_int("QPS_GEMV_WIDE_RB", 2);
     const bool wide = (c1 - c0) >= 4 * 256 * VecOf<T>::N;
-#define QPS_GR(TRI, TH) hipLaunchKernelGGL((k_gemv_rows<T, RB, TRI, TH>), grid, dim3(TH), 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1)
-    if (wide) { if (tri == 0) QPS_GR(0, 1024); else if (tri == 1) QPS_GR(1, 1024); else QPS_GR(2, 1024); }
-    else      { if (tri == 0) QPS_GR(0, 256);  else if (tri == 1) QPS_GR(1, 256);  else QPS_GR(2, 256); }
-#undef QPS_GR
+    if (!wide) { gemv_rows_launch<T, 4, 256>(st, S, ld, v, out, out0, alpha, beta, r0, r1, c0, c1, tri); return; }
+#define QPS_W(RB, TH) gemv_rows_launch<T, RB, TH>(st, S, ld, v, out, out0, alpha, beta, r0, r1, c0, c1, tri)
+    // RB must stay a multiple of the vector width (row-block starts are the 16-B aligned column starts of the triangle)
+    if (wide_th == 512) { if (wide_rb == 4) QPS_W(4, 512); else QPS_W(VecOf<T>::N == 2 ? 2 : 4, 512); }
+    else if (wide_th == 256) { if (wide_rb == 4) QPS_W(4, 256); else QPS_W(VecOf<T>::N == 2 ? 2 : 4, 256); }
+    else { if (wide_rb == 4) QPS_W(4, 1024); else QPS_W(VecOf<T>::N == 2 ? 2 : 4, 1024); }
+#undef QPS_W
 }
 
 int gemv_cols_tiles(int nrows) { return (nrows + GC_RT - 1) / GC_RT; }

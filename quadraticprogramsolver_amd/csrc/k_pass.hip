@@ -12,6 +12,8 @@
 // The x update (:56-57) rides along (workgroup 0; x is ping-ponged so no workgroup ever reads a buffer being written).
 // CHECK variant (every numItrConv-th iteration): additionally A x_new (second dot on the same tile), A'y_new (second
 // accumulator) and the primal-side inf-norms of CheckConvergence (:85,88,105), so the check re-reads neither A nor A'.
+#include <cstdlib>
+
 #include "qps_kernels.h"
 
 namespace qps {
@@ -222,7 +224,12 @@ void launch_pass(hipStream_t st, bool check, int G, const T* A, int64_t ld, int 
 
 }  // namespace
 
-template <typename T> int apass_max_np() { return 8 * 512 * VecOf<T>::N; }
+static int pass_threads() {
+    static int th = [] { const char* e = getenv("QPS_PASS_THREADS"); int v = e ? atoi(e) : 512; return v == 1024 ? 1024 : 512; }();
+    return th;
+}
+
+template <typename T> int apass_max_np() { return 8 * pass_threads() * VecOf<T>::N; }
 
 template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg) {
     if (NP > apass_max_np<T>() || MP <= 0) { *rows_per_wg = 0; return 0; }
@@ -233,21 +240,34 @@ template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg) {
     return (MP + rpw - 1) / rpw;
 }
 
-template <typename T>
-void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
-           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots) {
+template <typename T, int TH>
+void apass_th(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
+              T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots) {
     int rpw = 0;
     const int G = apass_plan<T>(NP, MP, &rpw);
-    constexpr int TH = 512;
     const int chunk = TH * VecOf<T>::N;
     const int kc = (NP + chunk - 1) / chunk;
 #define QPS_PASS(KC, R, RC) launch_pass<T, TH, KC, R, RC>(st, check, G, A, ld, NP, MP, rpw, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots)
     // (row tile of the plain variant, row tile of the check variant): sized so that neither spills
-    if (kc <= 1) QPS_PASS(1, 4, 4);
-    else if (kc <= 2) QPS_PASS(2, 4, 4);
-    else if (kc <= 4) QPS_PASS(4, 4, 2);
-    else QPS_PASS(8, 2, 1);
+    if (TH == 512) {
+        if (kc <= 1) QPS_PASS(1, 4, 4);
+        else if (kc <= 2) QPS_PASS(2, 4, 4);
+        else if (kc <= 4) QPS_PASS(4, 4, 2);
+        else QPS_PASS(8, 2, 1);
+    } else {   // 1024 threads: 4 waves per SIMD, 128 VGPRs per lane
+        if (kc <= 1) QPS_PASS(1, 4, 4);
+        else if (kc <= 2) QPS_PASS(2, 4, 2);
+        else if (kc <= 4) QPS_PASS(4, 2, 1);
+        else QPS_PASS(8, 1, 1);
+    }
 #undef QPS_PASS
+}
+
+template <typename T>
+void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
+           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots) {
+    if (pass_threads() == 1024) apass_th<T, 1024>(st, check, A, ld, NP, MP, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots);
+    else apass_th<T, 512>(st, check, A, ld, NP, MP, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots);
 }
 
 #define INST(T)                                                                                                            \
