@@ -1,0 +1,113 @@
+# QuadraticProgramSolverHIP.jl -- thin `ccall` layer over libqps_hip.so (C ABI: include/qps.h).
+#
+# NOT EXECUTED in this pipeline: neither the build container nor the GPU box has Julia.  All logic lives below the C
+# ABI; this file only marshals arguments, so that it can be reviewed by reading.  A maintainer of the reference drops it
+# next to SolveQuadraticProgram.jl and passes the sentinel pair to the unmodified call:
+#
+#     include("QuadraticProgramSolverHIP.jl")
+#     convFlag = SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, HipCholInit, HipChol!; ρ = 0.1, adptΡ = true)
+#
+# `SolveQuadraticProgram!` below is a method specialised on the sentinel types, so the reference's generic method
+# (SolveQuadraticProgram.jl:14) keeps serving every other plugin pair.
+
+const LIBQPS = get(ENV, "QPS_HIP_LIB", joinpath(@__DIR__, "..", "quadraticprogramsolver_amd", "libqps_hip.so"))
+
+# mirrors qps_params / qps_info of include/qps.h field by field
+struct QpsParams
+    numIterations::Int32; adptRho::Int32; numItrConv::Int32; numItrPolish::Int32; numItrMinres::Int32
+    linsys::Int32; trsvBlock::Int32; reuseFactor::Int32
+    epsAbs::Float64; epsRel::Float64; rho::Float64; sigma::Float64; alpha::Float64; delta::Float64
+    fctrRho::Float64; epsMinres::Float64; epsPcg::Float64
+    numItrPcg::Int32; loopVariant::Int32
+end
+mutable struct QpsInfo
+    convFlag::Int32; iterations::Int32; numRefactor::Int32; cgIterations::Int32
+    rhoFinal::Float64; rhoProposed::Float64; resPrim::Float64; resDual::Float64
+    tSetup::Float64; tLoop::Float64; tRefactor::Float64
+    QpsInfo() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+end
+
+struct HipCholInitT end;  const HipCholInit = HipCholInitT()      # dense reduced-form Cholesky on the device
+struct HipCholT end;      const HipChol! = HipCholT()
+struct HipCgInitT end;    const HipCgInit = HipCgInitT()          # CSR matrix-free CG on the device
+struct HipCgT end;        const HipCg! = HipCgT()
+
+function _check(status::Int32, h::Ptr{Cvoid} = C_NULL)
+    status == 0 && return
+    msg = unsafe_string(ccall((:qps_last_error, LIBQPS), Cstring, (Ptr{Cvoid},), h))
+    status in (1, 2, 3) ? throw(ArgumentError(msg)) : error(msg)
+end
+
+# SparseMatrixCSC{Float64,Int64} fields go through unchanged (colptr/rowval/nzval, index_base = 1)
+function _create(mP::SparseMatrixCSC{Float64,Int64}, vQ, mA::SparseMatrixCSC{Float64,Int64}, vL, vU; densePath::Bool, device = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    n, m = size(mP, 1), size(mA, 1)
+    GC.@preserve mP vQ mA vL vU begin
+        _check(ccall((:qps_create_csc, LIBQPS), Int32,
+            (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+            n, m, mP.colptr, mP.rowval, mP.nzval, mA.colptr, mA.rowval, mA.nzval, vQ, vL, vU,
+            Int32(1), Int32(densePath), Int32(0), Int32(device), h))
+    end
+    return h[]
+end
+function _create(mP::Matrix{Float64}, vQ, mA::Matrix{Float64}, vL, vU; densePath::Bool = true, device = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    n, m = size(mP, 1), size(mA, 1)
+    GC.@preserve mP vQ mA vL vU begin
+        _check(ccall((:qps_create_dense, LIBQPS), Int32,
+            (Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ref{Ptr{Cvoid}}),
+            n, m, mP, stride(mP, 2), mA, max(stride(mA, 2), 1), vQ, vL, vU, Int32(0), Int32(device), h))
+    end
+    return h[]
+end
+
+function _solve!(vX::Vector{Float64}, mP, vQ, mA, vL, vU, densePath::Bool;
+    numIterations = 5000, ϵAbs = 1e-6, ϵRel = 1e-6, ρ = 1, σ = 1e-6, α = 1.6, δ = 1e-6, adptΡ::Bool = false,
+    fctrΡ = 5, numItrConv = 25, numItrPolish = 10, ϵMinres = 1e-6, numItrMinres = 500, info = nothing)
+    h = _create(mP, Vector{Float64}(vQ), mA, Vector{Float64}(vL), Vector{Float64}(vU); densePath = densePath)
+    try
+        prm = QpsParams(numIterations, adptΡ, numItrConv, numItrPolish, numItrMinres, densePath ? 1 : 2, 0, 0,
+                        ϵAbs, ϵRel, ρ, σ, α, δ, fctrΡ, ϵMinres, 1e-6, 1000, 0)
+        inf = QpsInfo()
+        GC.@preserve vX _check(ccall((:qps_solve, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{QpsParams}, Ref{QpsInfo}),
+                                     h, vX, Ref(prm), inf), h)
+        info === nothing || (info[] = inf)
+        return ConvergenceFlag(inf.convFlag)     # the reference's own enum (SolveQuadraticProgram.jl:12)
+    finally
+        ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), h)
+    end
+end
+
+# Same positional order and keyword names as SolveQuadraticProgram.jl:14-17
+SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipCholInitT, ::HipCholT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, true; kw...)
+SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipCgInitT, ::HipCgT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, false; kw...)
+
+# Convenience form named in the project brief: SolveQuadraticProgram(P, q, A, l, u; ...) -> (x, flag)
+function SolveQuadraticProgram(mP, vQ, mA, vL, vU; kw...)
+    vX = zeros(size(mP, 1))
+    flag = SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, HipCholInit, HipChol!; kw...)
+    return vX, flag
+end
+
+# The plugin pair called literally by the UNMODIFIED reference loop (SolveQuadraticProgram.jl:36,54): host vectors in,
+# device linear solve, host vectors out.  tuSolver holds the handle; a finaliser destroys it.
+mutable struct HipLinSys
+    h::Ptr{Cvoid}
+    function HipLinSys(h)
+        s = new(h)
+        finalizer(x -> ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), x.h), s)
+    end
+end
+function (::HipCholInitT)(vX, mP, vQ, mA, ρ, ρ¹, σ, numElements, numConstraints)
+    h = _create(mP, Vector{Float64}(vQ), mA, zeros(numConstraints), zeros(numConstraints); densePath = true)
+    _check(ccall((:qps_linsys_init, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Float64, Int32, Int32), h, ρ, σ, 1, 0), h)
+    return zeros(numElements), zeros(numConstraints), Any[HipLinSys(h)]
+end
+function (::HipCholT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ)
+    h = tuSolver[1].h
+    GC.@preserve vXX vZZ vX vZ vY _check(ccall((:qps_linsys_solve, LIBQPS), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int32, Ptr{Float64}, Ptr{Float64}),
+        h, vX, vZ, vY, ρ, σ, Int32(changedΡ), vXX, vZZ), h)
+    return
+end
