@@ -1,8 +1,400 @@
-// k_sparse.hip -- CSR SpMV + matrix-free CG path (placeholder until the kernels land in this round).
+// k_sparse.hip -- CSR path: SpMV kernels and the device-resident matrix-free CG plugin.
+//
+// Reference: LinOpCgInit / LinOpCg! (LinearSystemSolvers.jl:145-186): the reduced operator
+//     u = P w + rho A'(A w) + sigma w                                   (:152-157)
+// is applied matrix-free inside IterativeSolvers.cg!(vXX, mL, vT, abstol = 1e-6, maxiter = 1000) (:179), x~ warm
+// started from the previous ADMM iteration, then z~ = A x~ (:181).  cg! itself is un-vendored and unpinned; the
+// published algorithm is restated (stop when ||r||_2 <= max(sqrt(eps) ||r0||_2, abstol), r0 = b - A x0).
+//
+// Storage: A twice as CSR (rows of A for A w; rows of A' -- which *is* the caller's CSC of A, taken over unchanged apart
+// from Int64 -> int32 and the index base -- for A' v) and P as CSR (symmetric, so its CSC is its CSR).  fp values,
+// int32 indices.  One sub-wave of LPR lanes walks a row with unit stride over (col, val) pairs (coalesced), x is gathered.
+// CG scalars (alpha, beta, residual, done flag) live in device memory: the host enqueues CG iterations in batches and
+// reads 32 bytes per batch; iterations enqueued past convergence return at their first instruction.
+#include <algorithm>
+
 #include "qps_internal.h"
+#include "qps_kernels.h"
+
 namespace qps {
-SolverBase* make_sparse_solver(int, int64_t, int64_t, int, const int64_t*, const int64_t*, const double*, const int64_t*,
-                               const int64_t*, const double*, const double*, const double*, const double*, int) {
-    throw QpsError(QPS_ERR_UNSUPPORTED, "CSR/CG path not built yet");
+
+namespace {
+
+struct CgState { double res2, prev2, tol, uc; int iters, done, maxiter, pad; };
+
+template <typename T> __device__ __forceinline__ T sub_sum(T v, int lpr) {
+    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+// out[row] = a * sum_k val[k] x[col[k]] + b0 v0[row] + b1 v1[row]
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void k_spmv(int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
+                                              const T* __restrict__ va, const T* __restrict__ x, T* __restrict__ out, T a,
+                                              const T* __restrict__ v0, T b0, const T* __restrict__ v1, T b1,
+                                              const CgState* __restrict__ st) {
+    if (st && st->done) return;
+    const int row = (blockIdx.x * 256 + threadIdx.x) / LPR, lane = threadIdx.x % LPR;
+    T s = T(0);
+    if (row < nrows) {
+        const int e = rp[row + 1];
+        for (int k = rp[row] + lane; k < e; k += LPR) s += va[k] * x[ci[k]];
+    }
+    s = sub_sum(s, LPR);
+    if (lane == 0 && row < nrows) {
+        T r = a * s;
+        if (v0) r += b0 * v0[row];
+        if (v1) r += b1 * v1[row];
+        out[row] = r;
+    }
+}
+
+// c = P u + rho A'(tm) + sigma u  (tm = A u), plus this block's share of dot(u, c)   LinearSystemSolvers.jl:152-157
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void k_op_reduced(int n, const int* __restrict__ Prp, const int* __restrict__ Pci,
+                                                    const T* __restrict__ Pva, const int* __restrict__ Arp,
+                                                    const int* __restrict__ Aci, const T* __restrict__ Ava,
+                                                    const T* __restrict__ u, const T* __restrict__ tm, T rho, T sigma,
+                                                    T* __restrict__ c, double* __restrict__ partial, const CgState* __restrict__ st) {
+    if (st && st->done) return;
+    __shared__ double sh[4];
+    const int row = (blockIdx.x * 256 + threadIdx.x) / LPR, lane = threadIdx.x % LPR;
+    T s = T(0), s2 = T(0);
+    if (row < n) {
+        int e = Prp[row + 1];
+        for (int k = Prp[row] + lane; k < e; k += LPR) s += Pva[k] * u[Pci[k]];
+        e = Arp[row + 1];
+        for (int k = Arp[row] + lane; k < e; k += LPR) s2 += Ava[k] * tm[Aci[k]];
+    }
+    s = sub_sum(s, LPR); s2 = sub_sum(s2, LPR);
+    double d = 0.0;
+    if (lane == 0 && row < n) {
+        const T ui = u[row];
+        const T ci = s + rho * s2 + sigma * ui;
+        c[row] = ci;
+        d = (double)ui * (double)ci;
+    }
+    d = block_sum_256(d, sh);
+    if (partial && threadIdx.x == 0) partial[blockIdx.x] = d;
+}
+
+// r = b - c, u = 0, partial ||r||^2
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_init(int n, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ r,
+                                                 T* __restrict__ u, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double d = 0.0;
+    if (i < n) { const T ri = b[i] - c[i]; r[i] = ri; u[i] = T(0); d = (double)ri * (double)ri; }
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = d;
+}
+__global__ __launch_bounds__(256) void k_cg_init_final(int nparts, const double* __restrict__ partial, CgState* st, double abstol, int maxiter) {
+    __shared__ double sh[4];
+    double d = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) d += partial[i];
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) {
+        const double residual = sqrt(d);
+        st->res2 = d; st->prev2 = 1.0;
+        st->tol = fmax(1.4901161193847656e-08 * residual, abstol);   // reltol = sqrt(eps(Float64))
+        st->iters = 0; st->maxiter = maxiter;
+        st->done = (!(residual <= st->tol) && 0 < maxiter) ? 0 : 1;
+    }
+}
+// u = r + beta u, beta = res2 / prev2
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_update_u(int n, const T* __restrict__ r, T* __restrict__ u, const CgState* __restrict__ st) {
+    if (st->done) return;
+    const T beta = (T)(st->res2 / st->prev2);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) u[i] = r[i] + beta * u[i];
+}
+// alpha = res2 / dot(u, c); x += alpha u; r -= alpha c; partial ||r||^2
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_update_xr(int n, int nparts_uc, const double* __restrict__ partial_uc,
+                                                      const T* __restrict__ u, const T* __restrict__ c, T* __restrict__ x,
+                                                      T* __restrict__ r, double* __restrict__ partial_rr, const CgState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    double uc = 0.0;
+    for (int i = threadIdx.x; i < nparts_uc; i += 256) uc += partial_uc[i];   // same order in every block -> same alpha
+    uc = block_sum_256(uc, sh);
+    const T alpha = (T)(st->res2 / uc);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double d = 0.0;
+    if (i < n) {
+        x[i] += alpha * u[i];
+        const T ri = r[i] - alpha * c[i];
+        r[i] = ri;
+        d = (double)ri * (double)ri;
+    }
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) partial_rr[blockIdx.x] = d;
+}
+__global__ __launch_bounds__(256) void k_cg_finish(int nparts, const double* __restrict__ partial_rr, CgState* st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    double d = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) d += partial_rr[i];
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) {
+        st->prev2 = st->res2; st->res2 = d; st->iters += 1;
+        const double residual = sqrt(d);
+        if (residual <= st->tol || st->iters >= st->maxiter) st->done = 1;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_axpby(int n, T a, const T* __restrict__ x, T b, const T* __restrict__ y, T* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+
+struct Csr { int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int lpr = 16; };
+
+int pick_lpr(int64_t nnz, int nrows) {
+    const double avg = nrows > 0 ? (double)nnz / nrows : 0.0;
+    int l = 4;
+    while (l < 64 && l * 4 < avg) l *= 2;   // about 4 non-zeros per lane
+    return l;
+}
+
+template <typename T> struct SparseSolver : SolverBase {
+    Csr A, At, P;
+    T *q = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr;
+    T *xx = nullptr, *zz = nullptr, *w = nullptr, *tt = nullptr, *cu = nullptr, *cr = nullptr, *cc = nullptr, *tm = nullptr;
+    T *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
+    double *part_uc = nullptr, *part_rr = nullptr; CgState* state = nullptr; CgState* state_host = nullptr;
+    unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
+    int nb_n = 0, nb_op = 0; int64_t cg_total = 0; int last_cg = 4;
+    double eps_pcg = 1e-6; int itr_pcg = 1000;
+    int cat_spmv, cat_op, cat_vec, cat_chk;
+
+    void upload_csr(Csr& M, int nrows, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
+        M.nrows = nrows; M.nnz = (int64_t)ci.size(); M.lpr = pick_lpr(M.nnz, nrows);
+        M.rp = dalloc<int>(nrows + 1); M.ci = dalloc<int>(M.nnz); M.va = dalloc<T>(M.nnz);
+        HIPC(hipMemcpy(M.rp, rp.data(), sizeof(int) * (nrows + 1), hipMemcpyHostToDevice));
+        if (M.nnz > 0) {
+            HIPC(hipMemcpy(M.ci, ci.data(), sizeof(int) * M.nnz, hipMemcpyHostToDevice));
+            std::vector<T> v(va.begin(), va.end());
+            HIPC(hipMemcpy(M.va, v.data(), sizeof(T) * M.nnz, hipMemcpyHostToDevice));
+        }
+    }
+    void upload_vec(const double* h, T* d, int64_t count) {
+        if (count <= 0) return;
+        HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, st));
+        convert_copy<T>(st, stage, d, count);
+        HIPC(hipStreamSynchronize(st));
+    }
+    void download_vec(const T* d, double* h, int64_t count) {
+        if (count <= 0) return;
+        convert_back<T>(st, d, stage, count);
+        HIPC(hipMemcpyAsync(h, stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+
+    SparseSolver(int dev, int64_t n_, int64_t m_, int dt, const int64_t* Pcp, const int64_t* Pri, const double* Pnz,
+                 const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* qh, const double* lh, const double* uh, int base) {
+        device = dev; n = n_; m = m_; dtype = dt; sparse = true;
+        HIPC(hipSetDevice(device));
+        HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        prof.st = st;
+        const int64_t pnnz = Pcp[n] - base, annz = Acp[n] - base;
+        if (pnnz > 2000000000LL || annz > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 non-zeros");
+        // P: CSC == CSR (symmetric, full storage).  A': rows of A' are the columns of A == the caller's CSC.
+        std::vector<int> prp(n + 1), pci(pnnz), atrp(n + 1), atci(annz), arp(m + 1, 0), aci(annz);
+        std::vector<double> pva(Pnz, Pnz + pnnz), atva(Anz, Anz + annz), ava(annz);
+        for (int64_t j = 0; j <= n; ++j) { prp[j] = (int)(Pcp[j] - base); atrp[j] = (int)(Acp[j] - base); }
+        for (int64_t k = 0; k < pnnz; ++k) pci[k] = (int)(Pri[k] - base);
+        for (int64_t k = 0; k < annz; ++k) { atci[k] = (int)(Ari[k] - base); arp[atci[k] + 1]++; }
+        for (int64_t i = 0; i < m; ++i) arp[i + 1] += arp[i];
+        {   // rows of A by a counting sort over the CSC (columns visited in order -> sorted column indices per row)
+            std::vector<int> pos(arp.begin(), arp.end() - 1);
+            for (int64_t j = 0; j < n; ++j)
+                for (int k = atrp[j]; k < atrp[j + 1]; ++k) { const int r = atci[k]; aci[pos[r]] = (int)j; ava[pos[r]] = atva[k]; pos[r]++; }
+        }
+        upload_csr(P, (int)n, prp, pci, pva);
+        upload_csr(At, (int)n, atrp, atci, atva);
+        upload_csr(A, (int)m, arp, aci, ava);
+        const int64_t nn = n + 64, mm = m + 64;
+        q = dalloc<T>(nn); x = dalloc<T>(nn); xp = dalloc<T>(nn); xx = dalloc<T>(nn); tt = dalloc<T>(nn);
+        cu = dalloc<T>(nn); cr = dalloc<T>(nn); cc = dalloc<T>(nn); Px = dalloc<T>(nn); Aty = dalloc<T>(nn);
+        l = dalloc<T>(mm); u = dalloc<T>(mm); z = dalloc<T>(mm); zp = dalloc<T>(mm); y = dalloc<T>(mm); zz = dalloc<T>(mm);
+        w = dalloc<T>(mm); tm = dalloc<T>(mm); Ax = dalloc<T>(mm);
+        nb_n = (int)((n + 255) / 256);
+        const int lpr_op = std::max(P.lpr, At.lpr); P.lpr = At.lpr = lpr_op;
+        nb_op = (int)((n * lpr_op + 255) / 256);
+        part_uc = dalloc<double>(nb_op + 64); part_rr = dalloc<double>(nb_n + 64);
+        state = reinterpret_cast<CgState*>(dalloc<double>(16));
+        HIPC(hipHostMalloc((void**)&state_host, sizeof(CgState)));
+        scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
+        HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
+        stage = dalloc<double>(std::max(nn, mm) + 64);
+        upload_vec(qh, q, n); upload_vec(lh, l, m); upload_vec(uh, u, m);
+        const double s = sizeof(T);
+        auto spmv_bytes = [&](const Csr& M, int cols) { return (double)M.nnz * (s + 4) + M.nrows * 4.0 + s * (M.nrows + cols); };
+        cat_spmv = prof.category("spmv(A / A')", 0.5 * (spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m)));
+        cat_op = prof.category("cg_iteration(A u, P u + rho A'. + sigma u, axpys)", spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m) + spmv_bytes(P, (int)n) + s * 10.0 * n);
+        cat_vec = prof.category("admm_update", s * (3.0 * n + 7.0 * m));
+        cat_chk = prof.category("check_convergence", spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m) + spmv_bytes(P, (int)n));
+    }
+    ~SparseSolver() override {
+        (void)hipSetDevice(device);
+        if (st) (void)hipStreamSynchronize(st);
+        void* ptrs[] = {A.rp, A.ci, A.va, At.rp, At.ci, At.va, P.rp, P.ci, P.va, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
+                        Ax, Px, Aty, part_uc, part_rr, state, scratch, res_dev, stage};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (res_host) (void)hipHostFree(res_host);
+        if (state_host) (void)hipHostFree(state_host);
+        if (st) (void)hipStreamDestroy(st);
+    }
+
+    void spmv(const Csr& M, const T* xin, T* out, T a, const T* v0, T b0, const T* v1, T b1, const CgState* stt) {
+        if (M.nrows <= 0) return;
+        const int grid = (int)(((int64_t)M.nrows * M.lpr + 255) / 256);
+        const T* va = static_cast<const T*>(M.va);
+#define QPS_SP(L) hipLaunchKernelGGL((k_spmv<T, L>), dim3(grid), dim3(256), 0, st, M.nrows, M.rp, M.ci, va, xin, out, a, v0, b0, v1, b1, stt)
+        switch (M.lpr) { case 4: QPS_SP(4); break; case 8: QPS_SP(8); break; case 16: QPS_SP(16); break; case 32: QPS_SP(32); break; default: QPS_SP(64); }
+#undef QPS_SP
+    }
+    // c = Op(uin) with tm = A uin; optional partial dot(uin, c)
+    void op_reduced(const T* uin, T* cout, double rho, double sigma, double* partial, const CgState* stt) {
+        if (m > 0) spmv(A, uin, tm, T(1), nullptr, T(0), nullptr, T(0), stt);
+        const T* pv = static_cast<const T*>(P.va); const T* av = static_cast<const T*>(At.va);
+#define QPS_OP(L) hipLaunchKernelGGL((k_op_reduced<T, L>), dim3(nb_op), dim3(256), 0, st, (int)n, P.rp, P.ci, pv, At.rp, At.ci, av, uin, tm, (T)rho, (T)sigma, cout, partial, stt)
+        switch (P.lpr) { case 4: QPS_OP(4); break; case 8: QPS_OP(8); break; case 16: QPS_OP(16); break; case 32: QPS_OP(32); break; default: QPS_OP(64); }
+#undef QPS_OP
+    }
+
+    // IterativeSolvers.cg!(xx, Op, tt; abstol = eps_pcg, maxiter = itr_pcg), xx warm started
+    int cg(double rho, double sigma) {
+        op_reduced(xx, cc, rho, sigma, nullptr, nullptr);
+        hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_n), dim3(256), 0, st, (int)n, tt, cc, cr, cu, part_rr);
+        hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, state, eps_pcg, itr_pcg);
+        int launched = 0, batch = std::max(1, std::min(last_cg + 1, 64));
+        for (;;) {
+            {
+                for (int b = 0; b < batch; ++b) {
+                    ProfScope ps(prof, cat_op, 2);
+                    hipLaunchKernelGGL((k_cg_update_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, cr, cu, state);
+                    op_reduced(cu, cc, rho, sigma, part_uc, state);
+                    hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_op, part_uc, cu, cc, xx, cr, part_rr, state);
+                    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, nb_n, part_rr, state);
+                }
+            }
+            launched += batch;
+            HIPC(hipMemcpyAsync(state_host, state, sizeof(CgState), hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            prof.harvest();
+            if (state_host->done || launched >= itr_pcg) break;
+            batch = std::min(std::max(batch, 4) * 2, 64);
+        }
+        last_cg = state_host->iters;
+        cg_total += state_host->iters;
+        return state_host->iters;
+    }
+
+    // LinOpCg! body (LinearSystemSolvers.jl:176-181)
+    void linear_solve(double rho, double sigma) {
+        if (m > 0) hipLaunchKernelGGL((k_axpby<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (int)m, (T)rho, z, T(-1), y, w);   // :176
+        {
+            ProfScope ps(prof, cat_spmv, 2);
+            if (m > 0) spmv(At, w, tt, T(1), x, (T)sigma, q, T(-1), nullptr);                        // :177-178
+            else hipLaunchKernelGGL((k_axpby<T>), dim3(nb_n), dim3(256), 0, st, (int)n, (T)sigma, x, T(-1), q, tt);
+        }
+        cg(rho, sigma);                                                                             // :179
+        {
+            ProfScope ps(prof, cat_spmv, 2);
+            if (m > 0) spmv(A, xx, zz, T(1), nullptr, T(0), nullptr, T(0), nullptr);                 // :181
+        }
+    }
+
+    void solve(double* xh, const qps_params& p, qps_info* info) override {
+        HIPC(hipSetDevice(device));
+        const double t0 = now_s();
+        double rho = p.rho; const double sigma = p.sigma, alpha = p.alpha;
+        eps_pcg = p.epsPcg; itr_pcg = p.numItrPcg;
+        const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;
+        int convFlag = QPS_CONV_NUM_ITR;
+        upload_vec(xh, x, n);
+        const size_t nb_ = sizeof(T) * (size_t)(n + 64), mb_ = sizeof(T) * (size_t)(m + 64);
+        HIPC(hipMemsetAsync(xp, 0, nb_, st)); HIPC(hipMemsetAsync(xx, 0, nb_, st));                 // LinOpCgInit: vXX = zeros (:147)
+        HIPC(hipMemsetAsync(z, 0, mb_, st)); HIPC(hipMemsetAsync(y, 0, mb_, st)); HIPC(hipMemsetAsync(zp, 0, mb_, st));
+        HIPC(hipStreamSynchronize(st));
+        const double t1 = now_s();
+        double rhorho = rho; int ii = 0, nref = 0; double resP = NAN, resD = NAN;
+        cg_total = 0; last_cg = 4;
+        const int NPv = (int)n, MPv = (int)m;
+        for (ii = 1; ii <= p.numIterations; ++ii) {
+            if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) { rho = rhorho; ++nref; }   // operator is matrix-free: nothing to rebuild
+            linear_solve(rho, sigma);
+            {
+                ProfScope ps(prof, cat_vec, 2);
+                admm_update<T>(st, NPv, MPv, xx, zz, x, xp, z, zp, y, l, u, (T)alpha, (T)rho);
+            }
+            if (ii % p.numItrConv == 0) {
+                {
+                    ProfScope ps(prof, cat_chk, 2);
+                    if (m > 0) spmv(A, x, Ax, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                    spmv(P, x, Px, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                    if (m > 0) spmv(At, y, Aty, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                    else HIPC(hipMemsetAsync(Aty, 0, nb_, st));
+                    CheckScalars cs{p.epsAbs, p.epsRel, epsAdmm, rho, rhorho, p.adptRho, convFlag};
+                    check_convergence<T>(st, (int)n, (int)m, Ax, Px, Aty, q, x, xp, z, zp, scratch, res_dev, cs);
+                }
+                HIPC(hipMemcpyAsync(res_host, res_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                prof.harvest();
+                resP = res_host[0]; resD = res_host[1]; rhorho = res_host[4]; convFlag = (int)res_host[5];
+                if (convFlag != QPS_CONV_NUM_ITR) break;
+            }
+        }
+        HIPC(hipStreamSynchronize(st));
+        prof.harvest();
+        const double t2 = now_s();
+        download_vec(x, xh, n);
+        if (info) {
+            info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
+            info->numRefactor = nref; info->cgIterations = (int)cg_total; info->rhoFinal = rho; info->rhoProposed = rhorho;
+            info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = 0;
+        }
+    }
+    void get_dual(double* zh, double* yh) override {
+        HIPC(hipSetDevice(device));
+        if (zh) download_vec(z, zh, m);
+        if (yh) download_vec(y, yh, m);
+    }
+    void linsys_init(double, double, int linsys, int) override {
+        HIPC(hipSetDevice(device));
+        if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG) throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles support QPS_LINSYS_CG only (create with dense_path=1 for the Cholesky path)");
+        HIPC(hipMemsetAsync(xx, 0, sizeof(T) * (size_t)(n + 64), st));                              // LinOpCgInit (:147)
+        cg_total = 0; last_cg = 4;
+    }
+    void linsys_solve(const double* xh, const double* zh, const double* yh, double rho, double sigma, int, double* xxh, double* zzh) override {
+        HIPC(hipSetDevice(device));
+        upload_vec(xh, x, n); upload_vec(zh, z, m); upload_vec(yh, y, m);
+        linear_solve(rho, sigma);
+        HIPC(hipStreamSynchronize(st));
+        download_vec(xx, xxh, n); download_vec(zz, zzh, m);
+    }
+};
+
+}  // namespace
+
+SolverBase* make_sparse_solver(int device, int64_t n, int64_t m, int dtype, const int64_t* Pcp, const int64_t* Pri,
+                               const double* Pnz, const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* q,
+                               const double* l, const double* u, int index_base) {
+    if (dtype == QPS_F64) return new SparseSolver<double>(device, n, m, dtype, Pcp, Pri, Pnz, Acp, Ari, Anz, q, l, u, index_base);
+    return new SparseSolver<float>(device, n, m, dtype, Pcp, Pri, Pnz, Acp, Ari, Anz, q, l, u, index_base);
+}
+
 }  // namespace qps

@@ -240,3 +240,62 @@ def test_full_size_properties_c2(gpu):
             assert abs(info["resDual"] - np.abs(P @ xk + q + A.T @ yk).max()) <= 1e-8 * max(1.0, info["resDual"])
             assert np.all(zk >= l - 1e-12) and np.all(zk <= u + 1e-12)
         assert rel(xs[0], xs[1]) <= 1e-9 and rel(xs[2], xs[1]) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CSR / matrix-free CG path (BASELINE config 3; LinearSystemSolvers.jl:145-186)
+# ------------------------------------------------------------------------------------------------------------------
+SPARSE_CASES = [(ProblemClass.randomQp, 200, 0), (ProblemClass.isotonicRegression, 300, 0),
+                (ProblemClass.portfolioOptimization, 200, 0), (ProblemClass.supportVectorMachine, 10, 0),
+                (ProblemClass.randomQp, 2000, 3000)]
+
+
+@pytest.mark.parametrize("pc,n,m", SPARSE_CASES)
+def test_cg_path_iterates_match_oracle(gpu, c_oracle, pc, n, m):
+    """With the inner tolerance driven to 1e-13 both CG implementations solve the linear system to fp64 accuracy, so the
+    ADMM iterates must agree tightly (the summation order inside the SpMVs differs)."""
+    P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 80 + int(pc)))
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
+        for K in (25, 50):
+            x = np.zeros(P.shape[0]); info = {}
+            prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, ϵPcg=1e-13, numItrPcg=5000, info=info)
+            z, y = prob.dual()
+            xo, io = c_oracle.solve(P, q, A, l, u, numIterations=K, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_CG_MATFREE,
+                                    epsPcg=1e-13, numItrPcg=5000)
+            assert info["cgIterations"] > 0
+            assert rel(x, xo) <= 1e-7 and rel(z, io["z"]) <= 1e-7 and rel(y, io["y"]) <= 1e-6
+
+
+@pytest.mark.parametrize("pc,n,m", SPARSE_CASES[:4])
+def test_cg_path_solutions(gpu, c_oracle, np_oracle, pc, n, m):
+    """Reference defaults of the CG plugins (ϵPcg = 1e-6, numItrPcg = 1000, LinearSystemSolvers.jl:164): inexact inner
+    solves, so parity is at solution level: same x* as the direct oracle within 1e-4 (inner abstol 1e-6 amplified by the
+    conditioning of the reduced operator)."""
+    P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 80 + int(pc)))
+    x = np.zeros(P.shape[0]); info = {}
+    flag = gpu.SolveQuadraticProgramInplace(x, P, q, A, l, u, gpu.HipCgInit, gpu.HipCg, numIterations=20000, ϵAbs=1e-6, ϵRel=1e-6,
+                                            ρ=0.1, adptΡ=True, info=info)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-6, epsRel=1e-6, rho=0.1, adptRho=True)
+    assert int(flag) in (2, 3) and io["convFlag"] in (2, 3)
+    assert np.abs(x - xo).max() <= 1e-4 * max(1.0, np.abs(xo).max())
+
+
+def test_cg_plugin_pair_in_isolation(gpu, c_oracle):
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.randomQp, 500, numConstraints=800, rng=make_rng(4, 4))
+    rng = make_rng(12, 0)
+    n, m = P.shape[0], A.shape[0]
+    Pd, Ad = P.toarray(), A.toarray()
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
+        prob.linsys_init(0.5, 1e-6)
+        x0 = np.zeros(n)                      # LinOpCgInit: vXX = zeros (:147); afterwards the previous x~ (warm start, :179)
+        for rho in (0.5, 7.0):
+            x, z, y = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(m)
+            xx, zz = np.zeros(n), np.zeros(m)
+            prob.linsys_solve(x, z, y, rho, 1e-6, rho != 0.5, xx, zz)
+            M = Pd + 1e-6 * np.eye(n) + rho * Ad.T @ Ad
+            rhs = 1e-6 * x - q + Ad.T @ (rho * z - y)
+            # IterativeSolvers stopping rule: ||r|| <= max(sqrt(eps) ||r0||, abstol = 1e-6), r0 = b - M x0
+            tol = max(1.4901161193847656e-08 * np.linalg.norm(rhs - M @ x0), 1e-6)
+            assert np.linalg.norm(M @ xx - rhs) <= 1.1 * tol
+            assert np.abs(zz - Ad @ xx).max() <= 1e-10 * max(1.0, np.abs(zz).max())
+            x0 = xx.copy()
