@@ -33,7 +33,7 @@ constexpr int GLD = 80;   // LDS row stride (elements): k-groups of a fragment r
 template <typename T, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                               int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
-                                              int64_t sA, int64_t sB, int64_t sC) {
+                                              int64_t sA, int64_t sB, int64_t sC, int ktri) {
     const int bj = blockIdx.x, bi = blockIdx.y;
     if (lower_only && bj > bi) return;
     A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = T(0);
     const int i0 = bi * GT, j0 = bj * GT;
-    for (int k0 = 0; k0 < K; k0 += GK) {
+    // ktri 1: opB is lower triangular (opB(k,j) = 0 for k < j) -> start at k = j0;  ktri 2: opA is lower triangular
+    // (opA(i,k) = 0 for k > i) -> stop after the diagonal tile of row block i0
+    const int kbeg = (ktri == 1) ? j0 : 0;
+    const int kend = (ktri == 2) ? min(K, i0 + GT) : K;
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
         // stage opA(i0.., k0..) as As[k][i] and opB(k0.., j0..) as Bs[k][j]; 4 elements per thread each
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -124,44 +128,119 @@ __global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restri
     M[o] = PI[o] + rho * AA[o];                                                   // LinearSystemSolvers.jl:114 / :128
 }
 
-// Cholesky of one 64 x 64 diagonal block + its inverse.  256 threads: thread (i = tid & 63, g = tid >> 6).
+// Cholesky of one 64 x 64 diagonal block (factor only).  256 threads: lane i = row, wave g = column group of 16, so
+// thread (i, g) keeps the 16 entries a[i][16g .. 16g+15] in registers.  The 16 columns of a panel live in ONE wave, so
+// the panel is factorised with wave64 shuffles only (no LDS, no barrier); the finished panel is then published through
+// LDS and the waves to its right apply the rank-16 update.  4 panels => 8 barriers per block instead of 128.
 template <typename T>
-__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, T* __restrict__ dinv, int* __restrict__ fail) {
-    __shared__ T L[64][65];
-    __shared__ T X[64][65];
-    const int tid = threadIdx.x, i = tid & 63, g = tid >> 6;
+__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail) {
+    __shared__ T Lp[64][17];
+    const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
     T* blk = M + (int64_t)kb * 64 * ld + kb * 64;
-    for (int r = g; r < 64; r += 4) L[r][i] = blk[(int64_t)r * ld + i];
-    __syncthreads();
-    for (int k = 0; k < 64; ++k) {
-        T d = L[k][k];
-        if (!(d > T(0))) { if (tid == 0) atomicCAS(fail, 0, kb * 64 + k + 1); d = T(1); }
-        d = sqrt(d);
-        __syncthreads();
-        if (g == 0) { if (i == k) L[k][k] = d; else if (i > k) L[i][k] = L[i][k] / d; }
-        __syncthreads();
-        // trailing update of the lower triangle: L[i][j] -= L[i][k] * L[j][k], k < j <= i
-        const T lik = L[i][k];
-        if (i > k)
-            for (int j = k + 1 + g; j <= i; j += 4) L[i][j] -= lik * L[j][k];
-        __syncthreads();
-    }
-    // inverse by forward substitution, one column per thread (threads 0..63)
-    if (g == 0) {
-        const int j = i;
-        for (int r = 0; r < 64; ++r) {
-            T s = (r == j) ? T(1) : T(0);
-            if (r >= j) {
-                for (int k = j; k < r; ++k) s -= L[r][k] * X[k][j];
-                X[r][j] = s / L[r][r];
-            } else X[r][j] = T(0);
+    T a[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) a[jj] = blk[(int64_t)i * ld + 16 * g + jj];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (g == p) {                                        // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                T d = __shfl(a[k], 16 * p + k, 64);
+                if (!(d > T(0))) { if (i == 0) atomicCAS(fail, 0, kb * 64 + 16 * p + k + 1); d = T(1); }
+                const T rs = T(1) / sqrt(d);
+                a[k] *= rs;                                  // l_ik for i >= k (row k itself: d * rs = sqrt(d))
+#pragma unroll
+                for (int j = k + 1; j < 16; ++j) {
+                    const T ljk = __shfl(a[k], 16 * p + j, 64);
+                    a[j] -= a[k] * ljk;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Lp[i][k] = a[k];
         }
+        __syncthreads();
+        if (g > p) {
+            T li[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) li[k] = Lp[i][k];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s += li[k] * Lp[16 * g + jj][k];   // same address for all lanes: broadcast
+                a[jj] -= s;
+            }
+        }
+        __syncthreads();
     }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = 16 * g + jj;
+        blk[(int64_t)i * ld + j] = (j <= i) ? a[jj] : T(0);
+    }
+}
+
+// Inverses of ALL 64 x 64 diagonal blocks of L in one launch (blockIdx.x = block): forward elimination on the identity,
+// row i accumulates -sum_{p<i} L[i][p] X[p][:] and is scaled by 1/L[i][i] when k reaches i.  Off the Cholesky critical path.
+template <typename T>
+__global__ __launch_bounds__(256) void k_inv64(const T* __restrict__ L, int64_t ld, T* __restrict__ dinv) {
+    __shared__ T Ls[64][65];
+    __shared__ T rowk[64];
+    const int kb = blockIdx.x;
+    const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const T* blk = L + (int64_t)kb * 64 * ld + kb * 64;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Ls[i][16 * g + jj] = blk[(int64_t)i * ld + 16 * g + jj];
     __syncthreads();
-    for (int r = g; r < 64; r += 4) {
-        blk[(int64_t)r * ld + i] = (i <= r) ? L[r][i] : T(0);
-        dinv[(int64_t)kb * 4096 + r * 64 + i] = X[r][i];
+    T x[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) x[jj] = (i == 16 * g + jj) ? T(1) : T(0);
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+        if (i == k) {
+            const T inv = T(1) / Ls[k][k];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) { x[jj] *= inv; rowk[16 * g + jj] = x[jj]; }
+        }
+        __syncthreads();
+        if (i > k) {
+            const T lik = Ls[i][k];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) x[jj] -= lik * rowk[16 * g + jj];
+        }
+        __syncthreads();
     }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) dinv[(int64_t)kb * 4096 + i * 64 + 16 * g + jj] = x[jj];
+}
+
+// Panel solve X * L11' = A21 (in place), one thread per row of A21: x_j = (a_j - sum_{k<j} x_k L11[j][k]) / L11[j][j].
+// L11 sits in LDS and every lane reads the same element at the same time (broadcast).
+template <typename T>
+__global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld, int kb, int nrows) {
+    __shared__ T Ls[64][65];
+    __shared__ T rdiag[64];
+    const int t = threadIdx.x;
+    const T* L11 = M + (int64_t)kb * 64 * ld + kb * 64;
+    for (int r = 0; r < 64; ++r) Ls[r][t] = L11[(int64_t)r * ld + t];
+    __syncthreads();
+    rdiag[t] = T(1) / Ls[t][t];
+    __syncthreads();
+    const int row = blockIdx.x * 64 + t;
+    if (row >= nrows) return;
+    T* ar = M + (int64_t)((kb + 1) * 64 + row) * ld + kb * 64;
+    T x[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) x[j] = ar[j];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        T s = x[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= x[k] * Ls[j][k];
+        x[j] = s * rdiag[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) ar[j] = x[j];
 }
 
 // S lower <- L lower with the 64-blocks on the diagonal replaced by their inverses; S upper <- 0
@@ -199,14 +278,14 @@ void import_colmajor(hipStream_t st, const double* src, int64_t lds, int rows, i
 
 template <typename T>
 void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda, bool ak, const T* B, int64_t ldb, bool bk,
-          T beta, T* C, int64_t ldc, bool lower_only, int batch, int64_t sA, int64_t sB, int64_t sC) {
+          T beta, T* C, int64_t ldc, bool lower_only, int batch, int64_t sA, int64_t sB, int64_t sC, int ktri) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
     dim3 grid(N / GT, M / GT, batch), block(256);
     const int lo = lower_only ? 1 : 0;
-    if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
-    else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
-    else if (!ak && bk) hipLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
-    else hipLaunchKernelGGL((k_gemm<T, false, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC);
+    if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
+    else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
+    else if (!ak && bk) hipLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
+    else hipLaunchKernelGGL((k_gemm<T, false, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
 }
 
 template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI) {
@@ -220,16 +299,17 @@ template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* 
     (void)hipMemsetAsync(fail_dev, 0, sizeof(int), st);
     const int nblk = NP / 64;
     for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL((k_potrf64<T>), dim3(1), dim3(256), 0, st, M, (int64_t)NP, kb, dinv, fail_dev);
+        hipLaunchKernelGGL((k_potrf64<T>), dim3(1), dim3(256), 0, st, M, (int64_t)NP, kb, fail_dev);
         const int rem = NP - (kb + 1) * 64;
         if (rem <= 0) break;
-        T* A21 = M + (int64_t)(kb + 1) * 64 * NP + kb * 64;
-        // L21 = A21 * inv(L11)'   (in place: each workgroup reads exactly the 64 x 64 block it overwrites)
-        gemm<T>(st, rem, 64, 64, T(1), A21, NP, true, dinv + (int64_t)kb * 4096, 64, true, T(0), A21, NP, false);
+        // L21 = A21 * inv(L11)'  by forward substitution, one thread per row
+        hipLaunchKernelGGL((k_trsm_panel<T>), dim3(rem / 64), dim3(64), 0, st, M, (int64_t)NP, kb, rem);
         // A22 -= L21 * L21'  (lower tiles only)
+        T* A21 = M + (int64_t)(kb + 1) * 64 * NP + kb * 64;
         T* A22 = M + (int64_t)(kb + 1) * 64 * NP + (kb + 1) * 64;
         gemm<T>(st, rem, rem, 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true);
     }
+    hipLaunchKernelGGL((k_inv64<T>), dim3(nblk), dim3(256), 0, st, M, (int64_t)NP, dinv);
 }
 
 template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp) {
@@ -241,16 +321,16 @@ template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, co
         while ((nfull + 1) * 2 * s <= NP) ++nfull;
         if (nfull > 0) {
             // tmp10 = L10 * inv00 ; S10 = -inv11 * tmp10     (batched over the pairs)
-            gemm<T>(st, s, s, s, T(1), L + (int64_t)s * NP, NP, true, S, NP, false, T(0), tmp + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride);
-            gemm<T>(st, s, s, s, T(-1), S + (int64_t)s * (NP + 1), NP, true, tmp + (int64_t)s * NP, NP, false, T(0), S + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride);
+            gemm<T>(st, s, s, s, T(1), L + (int64_t)s * NP, NP, true, S, NP, false, T(0), tmp + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride, 1);
+            gemm<T>(st, s, s, s, T(-1), S + (int64_t)s * (NP + 1), NP, true, tmp + (int64_t)s * NP, NP, false, T(0), S + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride, 2);
         }
         const int o = nfull * 2 * s;
         const int s2 = NP - o - s;
         if (s2 > 0) {   // ragged last pair: second block has s2 < s rows
             const T* L10 = L + (int64_t)(o + s) * NP + o;
             T* t10 = tmp + (int64_t)(o + s) * NP + o;
-            gemm<T>(st, s2, s, s, T(1), L10, NP, true, S + (int64_t)o * (NP + 1), NP, false, T(0), t10, NP, false);
-            gemm<T>(st, s2, s, s2, T(-1), S + (int64_t)(o + s) * (NP + 1), NP, true, t10, NP, false, T(0), S + (int64_t)(o + s) * NP + o, NP, false);
+            gemm<T>(st, s2, s, s, T(1), L10, NP, true, S + (int64_t)o * (NP + 1), NP, false, T(0), t10, NP, false, 1, 0, 0, 0, 1);
+            gemm<T>(st, s2, s, s2, T(-1), S + (int64_t)(o + s) * (NP + 1), NP, true, t10, NP, false, T(0), S + (int64_t)(o + s) * NP + o, NP, false, 1, 0, 0, 0, 2);
         }
     }
     hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64), dim3(256), 0, st, NP, S);
@@ -259,7 +339,7 @@ template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, co
 #define INST(T)                                                                                                        \
     template void import_colmajor<T>(hipStream_t, const double*, int64_t, int, int, T*, int64_t);                      \
     template void gemm<T>(hipStream_t, int, int, int, T, const T*, int64_t, bool, const T*, int64_t, bool, T, T*, int64_t, \
-                          bool, int, int64_t, int64_t, int64_t);                                                       \
+                          bool, int, int64_t, int64_t, int64_t, int);                                                  \
     template void make_PI<T>(hipStream_t, int, int, const T*, T, T*);                                                  \
     template void assemble_M<T>(hipStream_t, int, const T*, const T*, T, T*);                                          \
     template void cholesky<T>(hipStream_t, int, T*, T*, int*);                                                         \

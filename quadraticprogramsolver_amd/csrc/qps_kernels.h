@@ -73,7 +73,9 @@ void import_colmajor(hipStream_t st, const double* src, int64_t lds, int rows, i
 template <typename T>
 void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda, bool a_kcontig, const T* B, int64_t ldb,
           bool b_kcontig, T beta, T* C, int64_t ldc, bool lower_only, int batch = 1, int64_t sA = 0, int64_t sB = 0,
-          int64_t sC = 0);
+          int64_t sC = 0, int ktri = 0);
+// ktri: 1 = opB lower triangular (k loop starts at the tile's first column), 2 = opA lower triangular (k loop stops
+// after the tile's last row): structurally zero k-tiles are skipped.
 
 // M = PI + rho * AA (lower triangle incl. diagonal tiles; NP x NP)   (LinearSystemSolvers.jl:114,128)
 template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M);
