@@ -95,9 +95,11 @@ def main():
         if dom:
             dur = dom["seconds"] / dom["launches"]
             ach = dom["algo_bytes"] / dur / 1e9
+            traffic, traffic_src = pmc_traffic(dom["name"], cfg["dtype"])
             roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(dur * 1e6, 2),
-                        "algo_bytes_per_launch": dom["algo_bytes"], "launches_timed": dom["launches"]}
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "avg_launch_us": round(dur * 1e6, 2), "algo_bytes_per_launch": dom["algo_bytes"],
+                        "launches_timed": dom["launches"]}
         per_gpu = value / info.world_size
         out = {
             "metric": "ADMM iterations/sec", "value": round(value, 2), "unit": "iterations/s", "n_gpus": info.world_size,
@@ -137,6 +139,23 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_label, dtype):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and, in a
+    separate pass, --pmc WRITE_SIZE on this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters
+    cannot be read from inside the timed process, so the figure comes from profiles/ (or null when absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not (os.path.exists(path) and kernel_label.startswith("apass(fused") and dtype == "f64"):
+        return None, None
+    try:
+        d = json.load(open(path))
+        for name, v in d.items():
+            if name.startswith("k_apass<double") and name.endswith("false>"):
+                return v["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline(P, q, A, l, u, config):

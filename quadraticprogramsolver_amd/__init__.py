@@ -4,11 +4,11 @@ include/qps.h); this package is the host-side mirror of the reference interface 
 from .generator import (GenerateDenseBenchmarkQP, GenerateRandomQP, GenerateSparseBenchmarkQP, ProblemClass, make_rng,
                         sprandn)
 from .solver import (ConvergenceFlag, HipCg, HipCgInit, HipChol, HipCholF32, HipCholF32Init, HipCholInit,
-                     LinearSolverMode, QuadraticProgram, SolveQuadraticProgram, SolveQuadraticProgram_b,
+                     LinearSolverMode, QuadraticProgram, QuadraticProgramBatch, SolveQuadraticProgram, SolveQuadraticProgram_b,
                      SolveQuadraticProgramInplace)
 from ._lib import QpsError, QpsLibraryError
 
 __all__ = ["GenerateRandomQP", "GenerateDenseBenchmarkQP", "GenerateSparseBenchmarkQP", "ProblemClass", "make_rng",
-           "sprandn", "ConvergenceFlag", "LinearSolverMode", "QuadraticProgram", "SolveQuadraticProgram",
+           "sprandn", "ConvergenceFlag", "LinearSolverMode", "QuadraticProgram", "QuadraticProgramBatch", "SolveQuadraticProgram",
            "SolveQuadraticProgramInplace", "SolveQuadraticProgram_b", "HipCholInit", "HipChol", "HipCgInit", "HipCg",
            "HipCholF32Init", "HipCholF32", "QpsError", "QpsLibraryError"]

@@ -29,8 +29,11 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 template <typename T, int RB, int TRI, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_gemv_rows(const T* __restrict__ S, int64_t ld, const T* __restrict__ v,
                                                    T* __restrict__ out, const T* __restrict__ out0, T alpha, T beta,
-                                                   int r0, int c0, int c1) {
+                                                   int r0, int c0, int c1, BatchStride bs) {
     using V = typename VecOf<T>::type;
+    if (bs.active && !bs.active[blockIdx.y]) return;       // batched launch: blockIdx.y = QP index
+    S += (int64_t)blockIdx.y * bs.mat; v += (int64_t)blockIdx.y * bs.vin; out += (int64_t)blockIdx.y * bs.vout;
+    if (out0) out0 += (int64_t)blockIdx.y * bs.vout;
     constexpr int VN = VecOf<T>::N;
     constexpr int CHUNK = THREADS * VN;
     const int tid = threadIdx.x;
@@ -120,9 +123,13 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const T* __restrict__ S, int6
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int64_t part_ld, int ntiles,
                                                 const T* __restrict__ a0, T s0, const T* __restrict__ a1, T s1,
-                                                T* __restrict__ out, int ncols) {
+                                                T* __restrict__ out, int ncols, BatchStride bs) {
     using V = typename VecOf<T>::type;
     constexpr int VN = VecOf<T>::N;
+    if (bs.active && !bs.active[blockIdx.y]) return;       // batched: .mat = slab-set stride, .vin = a0/a1 stride, .vout = out stride
+    part += (int64_t)blockIdx.y * bs.mat; out += (int64_t)blockIdx.y * bs.vout;
+    if (a0) a0 += (int64_t)blockIdx.y * bs.vin;
+    if (a1) a1 += (int64_t)blockIdx.y * bs.vin;
     constexpr int CL = 16 / VN;          // lanes per 16-column group
     constexpr int TL = 256 / CL;         // slab lanes
     const int cl = threadIdx.x % CL, tl = threadIdx.x / CL;
@@ -198,7 +205,12 @@ __global__ __launch_bounds__(256) void k_check_norms(int n, int m, const T* __re
                                                      const T* __restrict__ Aty, const T* __restrict__ q,
                                                      const T* __restrict__ x, const T* __restrict__ xp,
                                                      const T* __restrict__ z, const T* __restrict__ zp,
-                                                     unsigned long long* __restrict__ slots, int dual_only) {
+                                                     unsigned long long* __restrict__ slots, int dual_only, BatchStride bs) {
+    if (bs.active && !bs.active[blockIdx.y]) return;       // batched: .vin = n-vector stride, .vout = m-vector stride
+    {
+        const int64_t on = (int64_t)blockIdx.y * bs.vin, om = (int64_t)blockIdx.y * bs.vout;
+        Ax += om; z += om; zp += om; Px += on; Aty += on; q += on; x += on; xp += on; slots += (int64_t)blockIdx.y * 16;
+    }
     unsigned long long v[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = 0ull;
@@ -229,8 +241,14 @@ __global__ __launch_bounds__(256) void k_check_norms(int n, int m, const T* __re
 __device__ __forceinline__ double jmax(double a, double b) { return (isnan(a) || isnan(b)) ? (double)NAN : (a > b ? a : b); }
 
 // Stage 2 (one thread): rho proposal + the two termination tests, in fp64 on the reduced scalars.
-__global__ void k_check_decide(const unsigned long long* __restrict__ slots, double* __restrict__ res, CheckScalars cs) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void k_check_decide(const unsigned long long* __restrict__ slots, double* __restrict__ res, CheckScalars cs,
+                               const double* __restrict__ rho_arr, const double* __restrict__ rhorho_arr,
+                               const int* __restrict__ active) {
+    if (threadIdx.x != 0) return;
+    const int b = blockIdx.x;                              // batched: one block per QP, per-QP rho / rhorho / flag
+    if (active && !active[b]) return;
+    slots += (int64_t)b * 16; res += (int64_t)b * 8;
+    if (rho_arr) { cs.rho = rho_arr[b]; cs.rhorho = rhorho_arr[b]; cs.convFlag = 1; }
     double nv[9];
     for (int k = 0; k < 9; ++k) nv[k] = __longlong_as_double((long long)slots[k]);
     const double MIN_VAL_RHO = 1e-3, MAX_VAL_RHO = 1e6;          // :81-82
@@ -272,23 +290,23 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 
 template <typename T, int RB, int TH>
 static void gemv_rows_launch(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta, int r0,
-                             int r1, int c0, int c1, int tri) {
-    dim3 grid((r1 - r0 + RB - 1) / RB);
-#define QPS_GR(TRI) hipLaunchKernelGGL((k_gemv_rows<T, RB, TRI, TH>), grid, dim3(TH), 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1)
+                             int r1, int c0, int c1, int tri, BatchStride bs) {
+    dim3 grid((r1 - r0 + RB - 1) / RB, bs.count);
+#define QPS_GR(TRI) hipLaunchKernelGGL((k_gemv_rows<T, RB, TRI, TH>), grid, dim3(TH), 0, st, S, ld, v, out, out0, alpha, beta, r0, c0, c1, bs)
     if (tri == 0) QPS_GR(0); else if (tri == 1) QPS_GR(1); else QPS_GR(2);
 #undef QPS_GR
 }
 
 template <typename T>
 void gemv_rows(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta, int r0, int r1,
-               int c0, int c1, int tri) {
+               int c0, int c1, int tri, BatchStride bs) {
     if (r1 <= r0) return;
     // wide rows: more threads per row block so that every load of the block is in flight at once
     static const int wide_th = env_int("QPS_GEMV_WIDE_THREADS", 512);   // measured best on C2: 512 threads x 2 rows
     static const int wide_rb = env_int("QPS_GEMV_WIDE_RB", 2);
     const bool wide = (c1 - c0) >= 4 * 256 * VecOf<T>::N;
-    if (!wide) { gemv_rows_launch<T, 4, 256>(st, S, ld, v, out, out0, alpha, beta, r0, r1, c0, c1, tri); return; }
-#define QPS_W(RB, TH) gemv_rows_launch<T, RB, TH>(st, S, ld, v, out, out0, alpha, beta, r0, r1, c0, c1, tri)
+    if (!wide) { gemv_rows_launch<T, 4, 256>(st, S, ld, v, out, out0, alpha, beta, r0, r1, c0, c1, tri, bs); return; }
+#define QPS_W(RB, TH) gemv_rows_launch<T, RB, TH>(st, S, ld, v, out, out0, alpha, beta, r0, r1, c0, c1, tri, bs)
     // RB must stay a multiple of the vector width (row-block starts are the 16-B aligned column starts of the triangle)
     if (wide_th == 512) { if (wide_rb == 4) QPS_W(4, 512); else QPS_W(VecOf<T>::N == 2 ? 2 : 4, 512); }
     else if (wide_th == 256) { if (wide_rb == 4) QPS_W(4, 256); else QPS_W(VecOf<T>::N == 2 ? 2 : 4, 256); }
@@ -311,8 +329,8 @@ int gemv_cols_partial(hipStream_t st, const T* S, int64_t ld, const T* va, const
 
 template <typename T>
 void colsum(hipStream_t st, const T* part, int64_t part_ld, int ntiles, const T* a0, T s0, const T* a1, T s1, T* out,
-            int ncols) {
-    hipLaunchKernelGGL((k_colsum<T>), dim3((ncols + 15) / 16), dim3(256), 0, st, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols);
+            int ncols, BatchStride bs) {
+    hipLaunchKernelGGL((k_colsum<T>), dim3((ncols + 15) / 16, bs.count), dim3(256), 0, st, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols, bs);
 }
 
 template <typename T>
@@ -325,14 +343,14 @@ void admm_update(hipStream_t st, int NP, int MP, const T* xx, const T* zz, T* x,
 template <typename T>
 void check_convergence(hipStream_t st, int n, int m, const T* Ax, const T* Px, const T* Aty, const T* q, const T* x,
                        const T* xp, const T* z, const T* zp, unsigned long long* scratch, double* res_dev, CheckScalars cs,
-                       int dual_only) {
-    if (!dual_only) (void)hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long), st);
+                       int dual_only, BatchStride bs, const double* rho_arr, const double* rhorho_arr) {
+    if (!dual_only) (void)hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long) * bs.count, st);
     const int N = n > m ? n : m;
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_check_norms<T>), dim3(blocks), dim3(256), 0, st, n, m, Ax, Px, Aty, q, x, xp, z, zp, scratch, dual_only);
-    hipLaunchKernelGGL(k_check_decide, dim3(1), dim3(64), 0, st, scratch, res_dev, cs);
+    hipLaunchKernelGGL((k_check_norms<T>), dim3(blocks, bs.count), dim3(256), 0, st, n, m, Ax, Px, Aty, q, x, xp, z, zp, scratch, dual_only, bs);
+    hipLaunchKernelGGL(k_check_decide, dim3(bs.count), dim3(64), 0, st, scratch, res_dev, cs, rho_arr, rhorho_arr, bs.active);
 }
 
 template <typename T> void fill(hipStream_t st, T* p, int64_t n, T v) {
@@ -349,12 +367,13 @@ template <typename T> void convert_back(hipStream_t st, const T* src, double* ds
 }
 
 #define INST(T)                                                                                                              \
-    template void gemv_rows<T>(hipStream_t, const T*, int64_t, const T*, T*, const T*, T, T, int, int, int, int, int);       \
+    template void gemv_rows<T>(hipStream_t, const T*, int64_t, const T*, T*, const T*, T, T, int, int, int, int, int, BatchStride); \
     template int gemv_cols_partial<T>(hipStream_t, const T*, int64_t, const T*, const T*, T, T, T*, int64_t, int, int);      \
-    template void colsum<T>(hipStream_t, const T*, int64_t, int, const T*, T, const T*, T, T*, int);                         \
+    template void colsum<T>(hipStream_t, const T*, int64_t, int, const T*, T, const T*, T, T*, int, BatchStride);            \
     template void admm_update<T>(hipStream_t, int, int, const T*, const T*, T*, T*, T*, T*, T*, const T*, const T*, T, T);   \
     template void check_convergence<T>(hipStream_t, int, int, const T*, const T*, const T*, const T*, const T*, const T*,    \
-                                       const T*, const T*, unsigned long long*, double*, CheckScalars, int);                      \
+                                       const T*, const T*, unsigned long long*, double*, CheckScalars, int, BatchStride,     \
+                                       const double*, const double*);                                                        \
     template void fill<T>(hipStream_t, T*, int64_t, T);                                                                      \
     template void convert_copy<T>(hipStream_t, const double*, T*, int64_t);                                                  \
     template void convert_back<T>(hipStream_t, const T*, double*, int64_t);

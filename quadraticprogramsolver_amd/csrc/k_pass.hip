@@ -56,8 +56,17 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
                                                    const T* __restrict__ xx, const T* __restrict__ x_old, T* __restrict__ x_new,
                                                    T* __restrict__ z, T* __restrict__ y, const T* __restrict__ l,
                                                    const T* __restrict__ u, T alpha, T rho, T* __restrict__ part,
-                                                   T* __restrict__ part2, int64_t part_ld, unsigned long long* __restrict__ slots) {
+                                                   T* __restrict__ part2, int64_t part_ld, unsigned long long* __restrict__ slots,
+                                                   PassBatch pb) {
     using PS = Pass<T, THREADS, KC, R, CHECK>;
+    if (pb.count > 1 || pb.active) {                       // batched launch: blockIdx.y = QP index
+        const int b = blockIdx.y;
+        if (pb.active && !pb.active[b]) return;
+        A += (int64_t)b * MP * ld; xx += (int64_t)b * NP; x_old += (int64_t)b * NP; x_new += (int64_t)b * NP;
+        z += (int64_t)b * MP; y += (int64_t)b * MP; l += (int64_t)b * MP; u += (int64_t)b * MP;
+        part += (int64_t)b * pb.slabs * part_ld; part2 += (int64_t)b * pb.slabs * part_ld; slots += (int64_t)b * 16;
+        if (pb.rho_arr) rho = (T)pb.rho_arr[b];
+    }
     using V = typename PS::V;
     constexpr int VN = PS::VN, CHUNK = PS::CHUNK, WAVES = PS::WAVES;
     const int tid = threadIdx.x, g = blockIdx.x;
@@ -217,9 +226,9 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
 template <typename T, int THREADS, int KC, int R, int RC>
 void launch_pass(hipStream_t st, bool check, int G, const T* A, int64_t ld, int NP, int MP, int rows_per_wg, const T* xx,
                  const T* x_old, T* x_new, T* z, T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2,
-                 int64_t part_ld, unsigned long long* slots) {
-    if (check) hipLaunchKernelGGL((k_apass<T, THREADS, KC, RC, true>), dim3(G), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots);
-    else hipLaunchKernelGGL((k_apass<T, THREADS, KC, R, false>), dim3(G), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots);
+                 int64_t part_ld, unsigned long long* slots, PassBatch pb) {
+    if (check) hipLaunchKernelGGL((k_apass<T, THREADS, KC, RC, true>), dim3(G, pb.count), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
+    else hipLaunchKernelGGL((k_apass<T, THREADS, KC, R, false>), dim3(G, pb.count), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
 }
 
 }  // namespace
@@ -231,10 +240,12 @@ static int pass_threads() {
 
 template <typename T> int apass_max_np() { return 8 * pass_threads() * VecOf<T>::N; }
 
-template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg) {
+template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg, int count) {
     if (NP > apass_max_np<T>() || MP <= 0) { *rows_per_wg = 0; return 0; }
     const int R = 4;
-    int rpw = (MP + 255) / 256;
+    // about one workgroup per CU over the whole launch (256 CUs), split evenly over the QPs of a batch
+    const int target = count >= 256 ? 1 : 256 / (count < 1 ? 1 : count);
+    int rpw = (MP + target - 1) / target;
     rpw = ((rpw + R - 1) / R) * R;
     *rows_per_wg = rpw;
     return (MP + rpw - 1) / rpw;
@@ -242,12 +253,14 @@ template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg) {
 
 template <typename T, int TH>
 void apass_th(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
-              T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots) {
+              T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots,
+              PassBatch pb) {
     int rpw = 0;
-    const int G = apass_plan<T>(NP, MP, &rpw);
+    const int G = apass_plan<T>(NP, MP, &rpw, pb.count);
+    pb.slabs = G;
     const int chunk = TH * VecOf<T>::N;
     const int kc = (NP + chunk - 1) / chunk;
-#define QPS_PASS(KC, R, RC) launch_pass<T, TH, KC, R, RC>(st, check, G, A, ld, NP, MP, rpw, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots)
+#define QPS_PASS(KC, R, RC) launch_pass<T, TH, KC, R, RC>(st, check, G, A, ld, NP, MP, rpw, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb)
     // (row tile of the plain variant, row tile of the check variant): sized so that neither spills
     if (TH == 512) {
         if (kc <= 1) QPS_PASS(1, 4, 4);
@@ -265,16 +278,17 @@ void apass_th(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP
 
 template <typename T>
 void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
-           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots) {
-    if (pass_threads() == 1024) apass_th<T, 1024>(st, check, A, ld, NP, MP, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots);
-    else apass_th<T, 512>(st, check, A, ld, NP, MP, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots);
+           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots,
+           PassBatch pb) {
+    if (pass_threads() == 1024) apass_th<T, 1024>(st, check, A, ld, NP, MP, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
+    else apass_th<T, 512>(st, check, A, ld, NP, MP, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
 }
 
 #define INST(T)                                                                                                            \
     template int apass_max_np<T>();                                                                                        \
-    template int apass_plan<T>(int, int, int*);                                                                            \
+    template int apass_plan<T>(int, int, int*, int);                                                                       \
     template void apass<T>(hipStream_t, bool, const T*, int64_t, int, int, const T*, const T*, T*, T*, T*, const T*, const T*, \
-                           T, T, T*, T*, int64_t, unsigned long long*);
+                           T, T, T*, T*, int64_t, unsigned long long*, PassBatch);
 INST(double)
 INST(float)
 #undef INST

@@ -279,9 +279,215 @@ template <typename T> struct DenseSolver : SolverBase {
 };
 
 // =================================================================================================================
+// Batch of independent dense QPs of one shape (BASELINE config 4).  All QPs advance in lock step through batched launches
+// (blockIdx.y = QP); rho, the proposed rho, the convergence flag and the active mask are per QP, exactly as if each QP
+// ran its own SolveQuadraticProgram! (the per-QP results are tested against per-QP oracle runs).
+// =================================================================================================================
+struct BatchSolverBase {
+    int device = 0; int64_t n = 0, m = 0; int count = 0; std::string err;
+    virtual ~BatchSolverBase() {}
+    virtual void solve_batch(double* x, const qps_params& p, qps_info* infos) = 0;
+};
+
+template <typename T> struct BatchedDenseSolver : BatchSolverBase {
+    hipStream_t st = nullptr;
+    int NP = 0, MP = 0, nb = 0, slabs = 0, rpw = 0, part_tiles = 0;
+    T *A = nullptr, *P = nullptr, *q = nullptr, *l = nullptr, *u = nullptr, *PI = nullptr, *AA = nullptr, *M = nullptr, *S = nullptr,
+      *tmp = nullptr, *dinv = nullptr;
+    T *x = nullptr, *xp = nullptr, *xres = nullptr, *z = nullptr, *y = nullptr, *xx = nullptr, *tt = nullptr, *yv = nullptr, *part = nullptr,
+      *part2 = nullptr, *part_tmp = nullptr, *Px = nullptr, *Aty = nullptr;
+    int* fail = nullptr; int* d_active = nullptr; double *d_rho = nullptr, *d_rhorho = nullptr;
+    unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
+    int* h_int = nullptr; double* h_dbl = nullptr;   // pinned staging for the small per-QP arrays
+    bool have_AA = false; double fac_sigma = -1;
+
+    BatchedDenseSolver(int dev, int cnt, int64_t n_, int64_t m_) {
+        device = dev; n = n_; m = m_; count = cnt;
+        HIPC(hipSetDevice(device));
+        HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        NP = roundup(n, 64); MP = roundup(m, 64);
+        slabs = apass_plan<T>(NP, MP, &rpw, count);
+        part_tiles = gemv_cols_tiles(MP);
+        const int64_t nn = (int64_t)NP * NP, c = count;
+        A = dalloc<T>(c * MP * NP); P = dalloc<T>(c * nn); PI = dalloc<T>(c * nn); AA = dalloc<T>(c * nn); M = dalloc<T>(c * nn);
+        S = dalloc<T>(c * nn); tmp = dalloc<T>(nn); dinv = dalloc<T>((int64_t)(NP / 64) * 4096);
+        q = dalloc<T>(c * NP); l = dalloc<T>(c * MP); u = dalloc<T>(c * MP);
+        x = dalloc<T>(c * NP); xp = dalloc<T>(c * NP); xres = dalloc<T>(c * NP); xx = dalloc<T>(c * NP); tt = dalloc<T>(c * NP);
+        yv = dalloc<T>(c * NP); Px = dalloc<T>(c * NP); Aty = dalloc<T>(c * NP); z = dalloc<T>(c * MP); y = dalloc<T>(c * MP);
+        part = dalloc<T>(c * slabs * NP); part2 = dalloc<T>(c * slabs * NP); part_tmp = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
+        fail = dalloc<int>(count + 4); d_active = dalloc<int>(count + 4); d_rho = dalloc<double>(count + 4); d_rhorho = dalloc<double>(count + 4);
+        scratch = dalloc<unsigned long long>(16 * c); res_dev = dalloc<double>(8 * c);
+        HIPC(hipHostMalloc((void**)&res_host, 8 * c * sizeof(double)));
+        HIPC(hipHostMalloc((void**)&h_int, (count + 4) * sizeof(int)));
+        HIPC(hipHostMalloc((void**)&h_dbl, 2 * (count + 4) * sizeof(double)));
+        stage = dalloc<double>(std::max<int64_t>((int64_t)MP * NP, nn) + 64);
+    }
+    ~BatchedDenseSolver() override {
+        (void)hipSetDevice(device);
+        if (st) (void)hipStreamSynchronize(st);
+        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, x, xp, xres, z, y, xx, tt, yv, part, part2, part_tmp, Px, Aty, fail, d_active,
+                        d_rho, d_rhorho, scratch, res_dev, stage};
+        for (void* p_ : ptrs) if (p_) (void)hipFree(p_);
+        if (res_host) (void)hipHostFree(res_host);
+        if (h_int) (void)hipHostFree(h_int);
+        if (h_dbl) (void)hipHostFree(h_dbl);
+        if (st) (void)hipStreamDestroy(st);
+    }
+    void put_vec(const double* h, T* d, int64_t cnt_) {
+        if (cnt_ <= 0) return;
+        HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)cnt_, hipMemcpyHostToDevice, st));
+        convert_copy<T>(st, stage, d, cnt_);
+        HIPC(hipStreamSynchronize(st));
+    }
+    void put_matrix(const double* h, int rows, int cols, T* d) {   // column-major rows x cols (ld = rows) -> row-major, ld NP
+        if (rows <= 0 || cols <= 0) return;
+        HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)rows * cols, hipMemcpyHostToDevice, st));
+        import_colmajor<T>(st, stage, rows, rows, cols, d, NP);
+        HIPC(hipStreamSynchronize(st));
+    }
+    void load_problem(int b, const double* Ph, const double* Ah, const double* qh, const double* lh, const double* uh) {
+        put_matrix(Ph, (int)n, (int)n, P + (int64_t)b * NP * NP);
+        put_matrix(Ah, (int)m, (int)n, A + (int64_t)b * MP * NP);
+        put_vec(qh, q + (int64_t)b * NP, n); put_vec(lh, l + (int64_t)b * MP, m); put_vec(uh, u + (int64_t)b * MP, m);
+    }
+    // LinearSystemSolvers.jl:112-114 / :127-129 for QP b (no host synchronisation; fail[b] is read later)
+    void factorize_one(int b, double rho, double sigma, bool rebuild) {
+        const int64_t nn = (int64_t)NP * NP;
+        T *Pb = P + b * nn, *Ab = A + (int64_t)b * MP * NP, *PIb = PI + b * nn, *AAb = AA + b * nn, *Mb = M + b * nn, *Sb = S + b * nn;
+        if (rebuild) {
+            make_PI<T>(st, (int)n, NP, Pb, (T)sigma, PIb);
+            gemm<T>(st, NP, NP, MP, T(1), Ab, NP, false, Ab, NP, false, T(0), AAb, NP, true);
+        }
+        assemble_M<T>(st, NP, PIb, AAb, (T)rho, Mb);
+        cholesky<T>(st, NP, Mb, dinv, fail + b);
+        build_sweep_matrix<T>(st, NP, nb, Mb, dinv, Sb, tmp);
+    }
+    void check_fail(const std::vector<int>& which) {
+        if (which.empty()) return;
+        HIPC(hipMemcpyAsync(h_int, fail, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        for (int b : which) if (h_int[b] != 0) {
+            char buf[256]; snprintf(buf, sizeof buf, "QP %d of the batch: Cholesky of P + sigma I + rho A'A broke down at column %d", b, h_int[b]);
+            throw QpsError(QPS_ERR_FACTORIZATION, buf);
+        }
+    }
+    void push_state(const std::vector<double>& rho, const std::vector<double>& rhorho, const std::vector<int>& active) {
+        for (int b = 0; b < count; ++b) { h_dbl[b] = rho[b]; h_dbl[count + 4 + b] = rhorho[b]; h_int[b] = active[b]; }
+        HIPC(hipMemcpyAsync(d_rho, h_dbl, sizeof(double) * count, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(d_rhorho, h_dbl + count + 4, sizeof(double) * count, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(d_active, h_int, sizeof(int) * count, hipMemcpyHostToDevice, st));
+        HIPC(hipStreamSynchronize(st));   // the pinned staging is reused
+    }
+
+    void solve_batch(double* xh, const qps_params& p, qps_info* infos) override {
+        HIPC(hipSetDevice(device));
+        const double t0 = now_s();
+        if (slabs <= 0) throw QpsError(QPS_ERR_UNSUPPORTED, "batched path needs m >= 1 and n within the fused-pass limit");
+        nb = pick_nb(p.trsvBlock, NP);
+        const double sigma = p.sigma, alpha = p.alpha;
+        const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;
+        std::vector<double> rho(count, p.rho), rhorho(count, p.rho), resP(count, NAN), resD(count, NAN), tref(count, 0.0);
+        std::vector<int> active(count, 1), conv(count, QPS_CONV_NUM_ITR), iters(count, p.numIterations), nref(count, 0), all(count);
+        for (int b = 0; b < count; ++b) all[b] = b;
+        HIPC(hipMemsetAsync(fail, 0, sizeof(int) * count, st));
+        const bool rebuild = !(p.reuseFactor && have_AA && fac_sigma == sigma);
+        for (int b = 0; b < count; ++b) factorize_one(b, p.rho, sigma, rebuild);                    // SolveQuadraticProgram.jl:36
+        check_fail(all);
+        have_AA = true; fac_sigma = sigma;
+        for (int b = 0; b < count; ++b) put_vec(xh + (int64_t)b * n, x + (int64_t)b * NP, n);
+        HIPC(hipMemsetAsync(z, 0, sizeof(T) * (size_t)count * MP, st));                             // :39
+        HIPC(hipMemsetAsync(y, 0, sizeof(T) * (size_t)count * MP, st));                             // :40
+        push_state(rho, rhorho, active);
+        const double t1 = now_s();
+        BatchStride bsS; bsS.count = count; bsS.mat = (int64_t)NP * NP; bsS.vin = NP; bsS.vout = NP; bsS.active = d_active;
+        BatchStride bsC; bsC.count = count; bsC.mat = (int64_t)slabs * NP; bsC.vin = NP; bsC.vout = NP; bsC.active = d_active;
+        BatchStride bsK; bsK.count = count; bsK.vin = NP; bsK.vout = MP; bsK.active = d_active;
+        PassBatch pb; pb.count = count; pb.slabs = slabs; pb.rho_arr = d_rho; pb.active = d_active;
+        int rhs_slabs = 0, nactive = count, ii = 0;
+        const int nblk = (NP + nb - 1) / nb;
+        for (ii = 1; ii <= p.numIterations && nactive > 0; ++ii) {                                  // :45
+            std::vector<int> changed;
+            if (p.adptRho)
+                for (int b = 0; b < count; ++b)
+                    if (active[b] && ((rhorho[b] * p.fctrRho < rho[b]) || (rhorho[b] > p.fctrRho * rho[b]))) {   // :47
+                        rho[b] = rhorho[b]; ++nref[b]; changed.push_back(b);
+                    }
+            if (!changed.empty()) {
+                const double ta = now_s();
+                for (int b : changed) {
+                    factorize_one(b, rho[b], sigma, false);
+                    if (rhs_slabs > 0) {   // slabs of A'(rho z - y) depend on rho: rebuild them for this QP (slab 0 = the sum, rest 0)
+                        T* pb_ = part + (int64_t)b * slabs * NP;
+                        gemv_cols_partial<T>(st, A + (int64_t)b * MP * NP, NP, z + (int64_t)b * MP, y + (int64_t)b * MP, (T)rho[b], T(-1), part_tmp, NP, MP, NP);
+                        colsum<T>(st, part_tmp, NP, part_tiles, nullptr, T(0), nullptr, T(0), pb_, NP);
+                        if (slabs > 1) HIPC(hipMemsetAsync(pb_ + NP, 0, sizeof(T) * (size_t)(slabs - 1) * NP, st));
+                    }
+                }
+                check_fail(changed);
+                push_state(rho, rhorho, active);
+                const double dt = (now_s() - ta) / changed.size();
+                for (int b : changed) tref[b] += dt;
+            }
+            const bool check = (ii % p.numItrConv == 0);
+            colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP, bsC);                  // LinearSystemSolvers.jl:136
+            for (int J = 0; J < nblk; ++J) {                                                        // forward sweep
+                const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
+                gemv_rows<T>(st, S, NP, tt, yv, nullptr, T(1), T(0), r0, r1, r0, r1, 1, bsS);
+                if (r1 < NP) gemv_rows<T>(st, S, NP, yv, tt, tt, T(-1), T(1), r1, NP, r0, r1, 0, bsS);
+            }
+            for (int J = nblk - 1; J >= 0; --J) {                                                   // backward sweep
+                const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
+                gemv_rows<T>(st, S, NP, yv, xx, nullptr, T(1), T(0), r0, r1, r0, r1, 2, bsS);
+                if (r0 > 0) gemv_rows<T>(st, S, NP, xx, yv, yv, T(-1), T(1), 0, r0, r0, r1, 0, bsS);
+            }
+            if (check) HIPC(hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long) * count, st));
+            apass<T>(st, check, A, NP, NP, MP, xx, x, xp, z, y, l, u, (T)alpha, T(1), part, part2, NP, scratch, pb);   // :56-61 + next rhs
+            std::swap(x, xp);
+            rhs_slabs = slabs;
+            if (check) {                                                                            // :63-69
+                colsum<T>(st, part2, NP, slabs, nullptr, T(0), nullptr, T(0), Aty, NP, bsC);
+                BatchStride bsP = bsS; bsP.mat = (int64_t)NP * NP;
+                gemv_rows<T>(st, P, NP, x, Px, nullptr, T(1), T(0), 0, NP, 0, NP, 0, bsP);
+                CheckScalars cs{p.epsAbs, p.epsRel, epsAdmm, 0.0, 0.0, p.adptRho, QPS_CONV_NUM_ITR};
+                check_convergence<T>(st, (int)n, (int)m, (const T*)nullptr, Px, Aty, q, x, xp, z, z, scratch, res_dev, cs, 1, bsK, d_rho, d_rhorho);
+                HIPC(hipMemcpyAsync(res_host, res_dev, 8 * sizeof(double) * count, hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                bool any_done = false;
+                for (int b = 0; b < count; ++b) {
+                    if (!active[b]) continue;
+                    const double* r = res_host + 8 * b;
+                    resP[b] = r[0]; resD[b] = r[1]; rhorho[b] = r[4]; conv[b] = (int)r[5];
+                    if (conv[b] != QPS_CONV_NUM_ITR) {
+                        active[b] = 0; iters[b] = ii; --nactive; any_done = true;
+                        HIPC(hipMemcpyAsync(xres + (int64_t)b * NP, x + (int64_t)b * NP, sizeof(T) * NP, hipMemcpyDeviceToDevice, st));
+                    }
+                }
+                push_state(rho, rhorho, active);
+                (void)any_done;
+            }
+        }
+        for (int b = 0; b < count; ++b)
+            if (active[b]) HIPC(hipMemcpyAsync(xres + (int64_t)b * NP, x + (int64_t)b * NP, sizeof(T) * NP, hipMemcpyDeviceToDevice, st));
+        HIPC(hipStreamSynchronize(st));
+        const double t2 = now_s();
+        for (int b = 0; b < count; ++b) {
+            convert_back<T>(st, xres + (int64_t)b * NP, stage, n);
+            HIPC(hipMemcpyAsync(xh + (int64_t)b * n, stage, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+            if (infos) {
+                qps_info& in = infos[b];
+                in.convFlag = conv[b]; in.iterations = iters[b]; in.numRefactor = nref[b]; in.cgIterations = 0;
+                in.rhoFinal = rho[b]; in.rhoProposed = rhorho[b]; in.resPrim = resP[b]; in.resDual = resD[b];
+                in.tSetup = t1 - t0; in.tLoop = t2 - t1; in.tRefactor = tref[b];   // wall time of the whole batch
+            }
+        }
+    }
+};
+
+// =================================================================================================================
 // handle plumbing
 // =================================================================================================================
-struct Handle { SolverBase* impl = nullptr; std::vector<SolverBase*> batch; int64_t n = 0, m = 0; std::string err; };
+struct Handle { SolverBase* impl = nullptr; std::vector<SolverBase*> batch; BatchSolverBase* fused_batch = nullptr; int64_t n = 0, m = 0; std::string err; };
 
 int fail_with(Handle* h, int code, const std::string& msg) {
     g_last_error = msg;
@@ -465,9 +671,34 @@ QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, cons
                                        const double* l, const double* u, int32_t dtype, int32_t device, qps_handle* out) {
     if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
     *out = nullptr;
-    if (count <= 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "batch count must be positive");
+    if (count <= 0 || count > 65535) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "batch count must be in 1..65535");
+    if (n <= 0 || m < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1 and m >= 0");
+    if (!P || !q || (m > 0 && (!A || !l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
+    if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
+    if (!all_finite(P, count * n * n, false) || !all_finite(q, count * n, false) || (m > 0 && !all_finite(A, count * m * n, false)))
+        return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P/A/q contain NaN/Inf");
+    if (m > 0 && (!all_finite(l, count * m, true) || !all_finite(u, count * m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
     Handle* h = new Handle(); h->n = n; h->m = m;
-    for (int64_t b = 0; b < count; ++b) {
+    int rpw = 0;
+    const int NPb = roundup(n, 64), MPb = roundup(m, 64);
+    const bool fusable = count > 1 && m > 0 && (dtype == QPS_F64 ? apass_plan<double>(NPb, MPb, &rpw, (int)count) : apass_plan<float>(NPb, MPb, &rpw, (int)count)) > 0;
+    if (fusable) {
+        int rc = guarded(nullptr, [&] {
+            auto load = [&](auto* s) {
+                h->fused_batch = s;
+                for (int64_t b = 0; b < count; ++b) s->load_problem((int)b, P + b * n * n, A + b * m * n, q + b * n, l + b * m, u + b * m);
+            };
+            if (dtype == QPS_F64) load(new BatchedDenseSolver<double>(device, (int)count, n, m));
+            else load(new BatchedDenseSolver<float>(device, (int)count, n, m));
+        });
+        if (rc != QPS_OK) { delete h->fused_batch; delete h; return rc; }
+        *out = reinterpret_cast<qps_handle>(h);
+        return QPS_OK;
+    }
+    for (int64_t b = 0; b < count; ++b) {   // shapes the fused pass does not cover: independent solvers, one after the other
         qps_handle one = nullptr;
         int rc = qps_create_dense(n, m, P + b * n * n, n, A ? A + b * m * n : nullptr, m, q + b * n, l ? l + b * m : nullptr,
                                   u ? u + b * m : nullptr, dtype, device, &one);
@@ -481,9 +712,11 @@ QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, cons
 
 QPS_API int32_t qps_solve_batch(qps_handle hh, double* x, const qps_params* p, qps_info* infos) {
     Handle* h = reinterpret_cast<Handle*>(hh);
-    if (!h || h->batch.empty()) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a batch handle");
+    if (!h || (h->batch.empty() && !h->fused_batch)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a batch handle");
+    if (!x) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "x_inout is NULL");
     int rc = validate_params(h, p);
     if (rc != QPS_OK) return rc;
+    if (h->fused_batch) return guarded(h, [&] { h->fused_batch->solve_batch(x, *p, infos); });
     for (size_t b = 0; b < h->batch.size(); ++b) {
         rc = guarded(h, [&] { h->batch[b]->solve(x + (int64_t)b * h->n, *p, infos ? infos + b : nullptr); });
         if (rc != QPS_OK) return rc;
@@ -522,6 +755,7 @@ QPS_API int32_t qps_destroy(qps_handle hh) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!h) return QPS_OK;
     delete h->impl;
+    delete h->fused_batch;
     for (auto* s : h->batch) delete s;
     delete h;
     return QPS_OK;

@@ -13,6 +13,11 @@
 
 namespace qps {
 
+// Batched launches (BASELINE config 4: many independent QPs of one shape per GPU): blockIdx.y = QP index, element strides
+// between consecutive QPs for the matrix / input-vector / output-vector operands, optional per-QP active mask.
+// Default-constructed = the single-QP launch (count 1, no offsets).
+struct BatchStride { int count = 1; int64_t mat = 0, vin = 0, vout = 0; const int* active = nullptr; };
+
 template <typename T> struct VecOf;
 template <> struct VecOf<double> { using type = double2; static constexpr int N = 2; };
 template <> struct VecOf<float>  { using type = float4;  static constexpr int N = 4; };
@@ -21,7 +26,7 @@ template <> struct VecOf<float>  { using type = float4;  static constexpr int N 
 // out[r] = alpha * sum_{c in [c0,c1), tri} S[r][c] v[c] + beta * out0[r]   for r in [r0, r1); tri: 0 none, 1 c<=r, 2 c>=r
 template <typename T>
 void gemv_rows(hipStream_t st, const T* S, int64_t ld, const T* v, T* out, const T* out0, T alpha, T beta,
-               int r0, int r1, int c0, int c1, int tri);
+               int r0, int r1, int c0, int c1, int tri, BatchStride bs = BatchStride());
 
 // part[t][c] = sum_{r in row tile t} S[r][c] * (ca*va[r] + cb*vb[r])  for c in [0, ncols); returns number of tiles
 template <typename T>
@@ -32,7 +37,7 @@ int gemv_cols_tiles(int nrows);
 // out[c] = s0*a0[c] + s1*a1[c] + sum_{t<ntiles} part[t][c]
 template <typename T>
 void colsum(hipStream_t st, const T* part, int64_t part_ld, int ntiles, const T* a0, T s0, const T* a1, T s1,
-            T* out, int ncols);
+            T* out, int ncols, BatchStride bs = BatchStride());   // bs.mat = stride between slab sets
 
 // SolveQuadraticProgram.jl:56-61 fused: xp=x; x=alpha*xx+(1-alpha)*x; zp=z; z=clamp(...); y=y+rho*(...)
 template <typename T>
@@ -44,19 +49,24 @@ void admm_update(hipStream_t st, int NP, int MP, const T* xx, const T* zz, T* x,
 struct CheckScalars { double epsAbs, epsRel, epsAdmm, rho, rhorho; int adptRho; int convFlag; };
 template <typename T>
 void check_convergence(hipStream_t st, int n, int m, const T* Ax, const T* Px, const T* Aty, const T* q, const T* x,
-                       const T* xp, const T* z, const T* zp, unsigned long long* scratch /*>=16 u64*/, double* res_dev,
-                       CheckScalars cs, int dual_only = 0);
+                       const T* xp, const T* z, const T* zp, unsigned long long* scratch /*>=16 u64 per QP*/, double* res_dev,
+                       CheckScalars cs, int dual_only = 0, BatchStride bs = BatchStride(), const double* rho_arr = nullptr,
+                       const double* rhorho_arr = nullptr);   // batched: bs.vin = n-vector stride, bs.vout = m-vector stride
 // dual_only = 1: the primal-side slots (0,2,3,7,8) were already filled by the fused pass (k_pass.hip); scratch is not
 // cleared and only the n-length norms are added before the decision.
 
 // ---- fused single pass over A (k_pass.hip) -----------------------------------------------------------------------
 // z~ = A x~, z/y update (SolveQuadraticProgram.jl:59-61), x_new = alpha x~ + (1-alpha) x_old (:57), slabs of
 // A'(rho z_new - y_new) for the next right-hand side; check = true adds A x_new norms, slabs of A'y_new, |x_new-x_old|.
-template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg);   // number of slabs (0: shape not supported)
+template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg, int count = 1);   // slabs per QP (0: unsupported)
 template <typename T> int apass_max_np();
+// Batched form: blockIdx.y = QP; strides are MP*ld (A), NP (n-vectors), MP (m-vectors), slabs*part_ld (slabs), 16 (slots);
+// rho_arr (double per QP) overrides the scalar rho; active masks finished QPs.
+struct PassBatch { int count = 1; int slabs = 0; const double* rho_arr = nullptr; const int* active = nullptr; };
 template <typename T>
 void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
-           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots);
+           T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots,
+           PassBatch pb = PassBatch());
 
 template <typename T> void fill(hipStream_t st, T* p, int64_t n, T v);
 template <typename T> void convert_copy(hipStream_t st, const double* src, T* dst, int64_t n);   // dst[i] = (T)src[i]

@@ -172,6 +172,62 @@ class QuadraticProgram:
         self.close()
 
 
+class QuadraticProgramBatch:
+    """A batch of independent dense QPs of one shape resident in HBM (qps_create_dense_batch / qps_solve_batch):
+    the per-problem loop of RunBenchmarks.jl:88-104 advanced in lock step by batched launches.  Every QP keeps its own
+    rho, proposed rho, convergence flag and stopping iteration, exactly as if solved alone."""
+
+    def __init__(self, problems, *, dtype="f64", device=0):
+        """``problems``: sequence of (mP, vQ, mA, vL, vU) tuples with identical shapes (dense or scipy sparse)."""
+        self.count = len(problems)
+        mP0, _, mA0, _, _ = problems[0]
+        self.n, self.m = mP0.shape[0], mA0.shape[0]
+        dense = lambda M: np.asarray(M.toarray() if sp.issparse(M) else M, dtype=np.float64)
+        for (mP, vQ, mA, vL, vU) in problems:
+            _validate_dims(self.n, mP, vQ, mA, vL, vU)
+            if mA.shape[0] != self.m:
+                raise ValueError("all problems of a batch must have the same number of constraints")
+        P = np.ascontiguousarray(np.stack([dense(p[0]).ravel(order="F") for p in problems]))
+        A = np.ascontiguousarray(np.stack([dense(p[2]).ravel(order="F") for p in problems])) if self.m > 0 else np.zeros((self.count, 1))
+        q = np.ascontiguousarray(np.stack([_vec(p[1], "vQ", self.n) for p in problems]))
+        l = np.ascontiguousarray(np.stack([_vec(p[3], "vL", self.m) for p in problems])) if self.m > 0 else np.zeros((self.count, 1))
+        u = np.ascontiguousarray(np.stack([_vec(p[4], "vU", self.m) for p in problems])) if self.m > 0 else np.zeros((self.count, 1))
+        h = C.c_void_p()
+        dt = {"f64": QPS_F64, "f32": QPS_F32}[dtype]
+        _lib.check(_lib.lib().qps_create_dense_batch(self.count, self.n, self.m, _dp(P), _dp(A), _dp(q), _dp(l), _dp(u), dt, device, C.byref(h)))
+        self._h = h
+
+    def solve(self, mX=None, *, numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, adptΡ=False, fctrΡ=5, numItrConv=25,
+              trsvBlock=0, reuseFactor=False):
+        """Returns (mX [count x n], list of ConvergenceFlag, list of info dicts).  ``mX`` (optional) holds the warm starts."""
+        X = np.zeros((self.count, self.n)) if mX is None else np.ascontiguousarray(mX, dtype=np.float64).copy()
+        p = _lib.default_params()
+        p.numIterations, p.epsAbs, p.epsRel = int(numIterations), float(ϵAbs), float(ϵRel)
+        p.rho, p.sigma, p.alpha = float(ρ), float(σ), float(α)
+        p.adptRho, p.fctrRho, p.numItrConv = int(bool(adptΡ)), float(fctrΡ), int(numItrConv)
+        p.trsvBlock, p.reuseFactor = int(trsvBlock), int(bool(reuseFactor))
+        infos = (QpsInfo * self.count)()
+        _lib.check(_lib.lib().qps_solve_batch(self._h, _dp(X), C.byref(p), infos), self._h)
+        return X, [ConvergenceFlag(i.convFlag) for i in infos], [i.as_dict() for i in infos]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().qps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Plugin pairs with the reference signature (LinearSystemSolvers.jl:16,28)
 # ------------------------------------------------------------------------------------------------------------------

@@ -194,23 +194,34 @@ def test_fp32_path(gpu, c_oracle):
 
 
 def test_batch_api(gpu, c_oracle):
-    cnt, n, m = 4, 96, 160
-    probs = [GenerateDenseBenchmarkQP(n, m, stream=10 + b, feasible=True) for b in range(cnt)]
-    import ctypes as C
-    from quadraticprogramsolver_amd import _lib
-    P = np.ascontiguousarray(np.stack([np.asfortranarray(p[0]).ravel(order="F") for p in probs]))
-    A = np.ascontiguousarray(np.stack([np.asfortranarray(p[2]).ravel(order="F") for p in probs]))
-    q = np.ascontiguousarray(np.stack([p[1] for p in probs])); l = np.ascontiguousarray(np.stack([p[3] for p in probs])); u = np.ascontiguousarray(np.stack([p[4] for p in probs]))
-    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    h = C.c_void_p()
-    _lib.check(_lib.lib().qps_create_dense_batch(cnt, n, m, dp(P), dp(A), dp(q), dp(l), dp(u), 0, 0, C.byref(h)))
-    prm = _lib.default_params(); prm.numIterations = 100; prm.epsAbs = 0.0; prm.epsRel = 0.0; prm.rho = 0.1
-    X = np.zeros((cnt, n)); infos = (_lib.QpsInfo * cnt)()
-    _lib.check(_lib.lib().qps_solve_batch(h, dp(X), C.byref(prm), infos), h)
-    _lib.lib().qps_destroy(h)
-    for b in range(cnt):
-        xo, io = c_oracle.solve(*[probs[b][k] for k in (0, 1, 2, 3, 4)], numIterations=100, epsAbs=0.0, epsRel=0.0, rho=0.1)
-        assert rel(X[b], xo) <= 1e-9 and infos[b].iterations == 100
+    """BASELINE config 4 shape in miniature: a batch advanced in lock step must reproduce per-QP independent runs --
+    fixed-K iterates, and (adaptive rho) per-QP flags, stopping iterations and refactor counts."""
+    cnt, n, m = 5, 96, 160
+    probs = [GenerateDenseBenchmarkQP(n, m, stream=10 + b, feasible=(b != 2)) for b in range(cnt)]   # QP 2: infeasible draw
+    with gpu.QuadraticProgramBatch(probs) as batch:
+        X, flags, infos = batch.solve(numIterations=100, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
+        for b in range(cnt):
+            xo, io = c_oracle.solve(*probs[b], numIterations=100, epsAbs=0.0, epsRel=0.0, rho=0.1)
+            assert rel(X[b], xo) <= 1e-9 and infos[b]["iterations"] == 100 and int(flags[b]) == 1
+            assert abs(infos[b]["resPrim"] - io["resPrim"]) <= 1e-9 * max(1.0, io["resPrim"])
+        X, flags, infos = batch.solve(numIterations=3000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True)
+        its = set()
+        for b in range(cnt):
+            xo, io = c_oracle.solve(*probs[b], numIterations=3000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
+            assert int(flags[b]) == io["convFlag"] and infos[b]["iterations"] == io["iterations"], (b, infos[b], io["iterations"])
+            assert infos[b]["numRefactor"] == io["numRefactor"]
+            assert np.abs(X[b] - xo).max() <= ABS_DEV_THR
+            its.add(io["iterations"])
+        assert len(its) > 1      # the QPs really stop at different iterations
+    # warm starts + the fallback path (m = 0 is outside the fused pass: independent solvers behind the same API)
+    rng = make_rng(8, 8)
+    free = []
+    for b in range(3):
+        Mx = rng.standard_normal((20, 20)); free.append((Mx.T @ Mx + np.eye(20), rng.standard_normal(20), np.zeros((0, 20)), np.zeros(0), np.zeros(0)))
+    with gpu.QuadraticProgramBatch(free) as batch:
+        X, flags, infos = batch.solve(numIterations=5000, ϵAbs=1e-9, ϵRel=1e-9)
+        for b in range(3):
+            assert np.abs(X[b] - np.linalg.solve(free[b][0], -free[b][1])).max() <= 1e-6
 
 
 def test_full_size_properties_c2(gpu):

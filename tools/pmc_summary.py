@@ -1,0 +1,21 @@
+"""Per-kernel HBM traffic from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units).
+gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced
+streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores."""
+import csv, sys, re, json, collections
+def load(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        mm = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"]); name = mm.group(1) if mm else r["Kernel_Name"]
+        d[name].append(float(r["Counter_Value"]))
+    return d
+f, w = load(sys.argv[1]), load(sys.argv[2])
+out = {}
+for k in sorted(f, key=lambda k: -sum(f[k])):
+    if not k.startswith("k_"): continue
+    fetch_kib = sum(f[k]) / len(f[k]); write_kib = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)
+    out[k] = {"launches": len(f[k]), "FETCH_SIZE_KiB_raw_per_launch": round(fetch_kib, 1), "WRITE_SIZE_KiB_per_launch": round(write_kib, 1),
+              "hbm_read_bytes_corrected_x2": round(fetch_kib * 1024 * 2), "hbm_write_bytes": round(write_kib * 1024),
+              "hbm_bytes_per_launch": round(fetch_kib * 1024 * 2 + write_kib * 1024)}
+    print(f"{k:42s} launches {len(f[k]):5d} fetch(raw) {fetch_kib/1024:9.2f} MiB  write {write_kib/1024:8.2f} MiB  -> traffic (2x fetch + write) {out[k]['hbm_bytes_per_launch']/1e6:9.2f} MB")
+if len(sys.argv) > 3:
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
