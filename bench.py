@@ -5,7 +5,7 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one qps_solve() of --iters ADMM iterations (ϵAbs = ϵRel = 0, adptΡ off, reference defaults otherwise) on a
+A "step" is one qps_solve() of --iters (default 500) ADMM iterations (ϵAbs = ϵRel = 0, adptΡ off, reference defaults otherwise) on a
 problem already resident in HBM with its factorisation cached (setup is reported separately).
 Rank 0 prints ONE JSON line.
 """
@@ -25,6 +25,8 @@ CONFIGS = {
     "c2": dict(n=4096, m=8192, dtype="f64", label="dense n=4096 m=8192 fp64 single QP (BASELINE configs[1])"),
     "c5": dict(n=4096, m=8192, dtype="f32", label="dense n=4096 m=8192 fp32, rho-update + refactor every 50 its (configs[4])"),
     "c1": dict(n=64, m=128, dtype="f64", label="dense n=64 m=128 fp64 (configs[0] shape, plumbing)"),
+    "c3": dict(n=50000, m=100000, dtype="f64", label="sparse P,A n=50k m=100k ~0.1% nnz fp64, CSR SpMV + matrix-free CG (configs[2])"),
+    "c4": dict(n=1024, m=2048, dtype="f64", batch=256, label="batch of 256 dense n=1024 m=2048 QPs sharded across the ranks (configs[3])"),
 }
 
 
@@ -33,12 +35,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=100, help="ADMM iterations per step")
+    ap.add_argument("--iters", type=int, default=500, help="ADMM iterations per step")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--trsv-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-eps", action="store_true")
-    ap.add_argument("--profile-level", type=int, default=1, help="1: HIP-event bracket the dominant kernel only; 2: all")
+    ap.add_argument("--profile-level", type=int, default=1,
+                    help="1: HIP-event bracket the dominant kernel on every 10th iteration; 2: every launch of every kernel")
     args = ap.parse_args()
 
     import torch  # first: keeps a single HIP runtime in the process (torch bundles its own libamdhip64)
@@ -54,9 +57,11 @@ def main():
     n, m = cfg["n"], cfg["m"]
     s = 8 if cfg["dtype"] == "f64" else 4
 
+    device = info.local_rank if torch.cuda.device_count() > info.local_rank else 0
+    if args.config in ("c3", "c4"):
+        return side_config(args, cfg, info, backend, device, qps, qd, np, torch)
     # synthetic input: randomQp at density 1.0, seed 1234, one independent stream per rank (weak scaling)
     P, q, A, l, u = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank)
-    device = info.local_rank if torch.cuda.device_count() > info.local_rank else 0
     prob = qps.QuadraticProgram(P, q, A, l, u, dtype=cfg["dtype"], device=device)
     solve_kw = dict(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, trsvBlock=args.trsv_block, reuseFactor=True)
     if args.config == "c5":
@@ -135,6 +140,66 @@ def main():
     prob.close()
     if info.rank == 0:
         print(json.dumps(out), flush=True)
+    if info.world_size > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def side_config(args, cfg, info, backend, device, qps, qd, np, torch):
+    """Configs that are not the headline line: c3 (CSR/CG, replicas) and c4 (the 256-QP batch cut into contiguous slabs,
+    one per rank, no collective).  Same timing contract: W warm-up steps, K timed steps between barrier + synchronize."""
+    n, m = cfg["n"], cfg["m"]
+    sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
+    if args.iters == 500:
+        args.iters = 100          # side configs: shorter steps
+    if args.config == "c4":
+        begin, end = qd.shard_range(cfg["batch"], info.rank, info.world_size)      # QP b -> rank b // ceil(256 / world)
+        probs = [qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b) for b in range(begin, end)]
+        solver = qps.QuadraticProgramBatch(probs, dtype=cfg["dtype"], device=device)
+        run = lambda: solver.solve(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, reuseFactor=True)
+        units_per_step = (end - begin) * args.iters
+        algo_bytes_per_unit = 8 * (m * n + n * n) + 8 * (6 * n + 10 * m)
+    else:
+        P, q, A, l, u = qps.GenerateSparseBenchmarkQP(n, m, seed=1234 + info.rank)
+        solver = qps.QuadraticProgram(P, q, A, l, u, linsys="cg", dtype=cfg["dtype"], device=device)
+        cg = {"n": 0}
+        def run():
+            x = np.zeros(n); si = {}
+            solver.solve(x, numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, info=si)
+            cg["n"] += si["cgIterations"]
+        units_per_step = args.iters
+        algo_bytes_per_unit = None
+    run()
+    for _ in range(args.warmup):
+        run()
+    if args.config == "c3":
+        cg["n"] = 0
+    qd.barrier(info); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync(); qd.barrier(info)
+    elapsed = time.perf_counter() - t0
+    value, tmax = qd.gather_timings(info, elapsed, units_per_step * args.steps)
+    if info.rank == 0:
+        out = {"metric": "ADMM iterations/sec" + (" (QP-iterations, summed over the batch)" if args.config == "c4" else ""),
+               "value": round(value, 2), "unit": "iterations/s", "n_gpus": info.world_size, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(tmax / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+               "config": {"workload": cfg["label"], "n": n, "m": m, "admm_iterations_per_step": args.iters, "dist_backend": backend,
+                          "parallelism": (f"256 QPs in {info.world_size} contiguous slab(s), no collective" if args.config == "c4"
+                                          else f"replicas x{info.world_size}")},
+               "roofline": None, "cpu_baseline": None}
+        if algo_bytes_per_unit:
+            per_gpu = value / info.world_size
+            out["loop_roofline"] = {"algo_bytes_per_iteration": algo_bytes_per_unit, "achieved_GBs": round(algo_bytes_per_unit * per_gpu / 1e9, 1),
+                                    "frac_of_8TBs": round(algo_bytes_per_unit * per_gpu / 1e9 / HBM_PEAK_GBS, 4)}
+        if args.config == "c3":
+            out["cg_iterations_per_s"] = round(cg["n"] / elapsed, 1)
+            out["cg_iterations_per_admm_iteration"] = round(cg["n"] / (units_per_step * args.steps), 2)
+        print(json.dumps(out), flush=True)
+    solver.close()
     if info.world_size > 1:
         import torch.distributed as dist
         dist.barrier()
