@@ -1,14 +1,14 @@
 """MI355X-native ADMM quadratic-program solver: drop-in for the SolveQuadraticProgram.jl + LinearSystemSolvers.jl path
 of RoyiAvital/QuadraticProgramSolver.  The compute lives in libqps_hip.so (hand-written HIP for gfx950, C ABI in
 include/qps.h); this package is the host-side mirror of the reference interface plus the GenerateRandomQP harness."""
-from .generator import (GenerateDenseBenchmarkQP, GenerateRandomQP, GenerateSparseBenchmarkQP, ProblemClass, make_rng,
-                        sprandn)
+from .generator import (GenerateDenseBenchmarkQP, GenerateRandomQP, GenerateSparseBenchmarkQP, LoadQpModel, ProblemClass,
+                        SaveQpModel, make_rng, sprandn)
 from .solver import (ConvergenceFlag, HipCg, HipCgInit, HipChol, HipCholF32, HipCholF32Init, HipCholInit,
                      LinearSolverMode, QuadraticProgram, QuadraticProgramBatch, SolveQuadraticProgram, SolveQuadraticProgram_b,
                      SolveQuadraticProgramInplace)
 from ._lib import QpsError, QpsLibraryError
 
 __all__ = ["GenerateRandomQP", "GenerateDenseBenchmarkQP", "GenerateSparseBenchmarkQP", "ProblemClass", "make_rng",
-           "sprandn", "ConvergenceFlag", "LinearSolverMode", "QuadraticProgram", "QuadraticProgramBatch", "SolveQuadraticProgram",
+           "sprandn", "SaveQpModel", "LoadQpModel", "ConvergenceFlag", "LinearSolverMode", "QuadraticProgram", "QuadraticProgramBatch", "SolveQuadraticProgram",
            "SolveQuadraticProgramInplace", "SolveQuadraticProgram_b", "HipCholInit", "HipChol", "HipCgInit", "HipCg",
            "HipCholF32Init", "HipCholF32", "QpsError", "QpsLibraryError"]

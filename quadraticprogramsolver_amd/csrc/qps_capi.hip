@@ -284,7 +284,7 @@ template <typename T> struct DenseSolver : SolverBase {
 // =================================================================================================================
 // Batch of independent dense QPs of one shape (BASELINE config 4).  All QPs advance in lock step through batched launches
 // (blockIdx.y = QP); rho, the proposed rho, the convergence flag and the active mask are per QP, exactly as if each QP
-// ran its own SolveQuadraticProgram! (the per-QP results are tested against per-QP oracle runs).
+// ran its own SolveQuadraticProgram! (the tests compare every QP of a batch with its own stand-alone run).
 // =================================================================================================================
 struct BatchSolverBase {
     int device = 0; int64_t n = 0, m = 0; int count = 0; std::string err;

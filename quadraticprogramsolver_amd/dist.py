@@ -30,8 +30,13 @@ def shard_range(total: int, rank: int, world_size: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def init_process_group(info: RankInfo, prefer: str = "nccl"):
-    """Returns the backend actually in use ("nccl" == RCCL on ROCm, or "gloo"), or None for a single process."""
+def init_process_group(info: RankInfo, prefer: str | None = None):
+    """Returns the backend actually in use ("gloo", or "nccl" == RCCL on ROCm), or None for a single process.
+
+    Default is gloo: the ADMM path has no exchange step, the only traffic is a barrier and two scalars per timed
+    region, and keeping torch off the GPU leaves a single HIP context per rank (the solver's).  QPS_DIST_BACKEND=nccl
+    (or prefer="nccl") routes those scalars through RCCL instead."""
+    prefer = prefer or os.environ.get("QPS_DIST_BACKEND", "gloo")
     if info.world_size <= 1:
         return None
     import torch

@@ -221,3 +221,26 @@ def GenerateSparseBenchmarkQP(numElements: int, numConstraints: int, *, densityA
     vI = rng.random(m) <= 0.15
     vU[vI] = 1.0
     return mP, vQ, mA, vL, vU
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Problem interchange.  The reference's only fixture hook is ``QpModel.mat`` with the keys
+# mP, vQ, mA, vL, vU (SolveQuadraticProgramUnitTest.m:83-85 writes it, SolveQuadraticProgramUnitTest.jl:49-54 reads it).
+# Writing the same MAT-v5 container lets anyone with Julia (MAT.jl) or MATLAB run the reference on exactly the inputs
+# this build was measured on, which is what closes the "parity unpinned" gap outside this pipeline.
+# ---------------------------------------------------------------------------------------------------------------------
+def SaveQpModel(fileName: str, mP, vQ, mA, vL, vU) -> None:
+    """Write ``QpModel.mat`` (MAT v5; sparse matrices stay sparse CSC, vectors are n x 1 columns as MATLAB/Julia expect)."""
+    import scipy.io as sio
+    col = lambda v: np.asarray(v, dtype=np.float64).reshape(-1, 1)
+    mat = lambda M: sp.csc_matrix(M, dtype=np.float64) if sp.issparse(M) else np.asarray(M, dtype=np.float64)
+    sio.savemat(fileName, {"mP": mat(mP), "vQ": col(vQ), "mA": mat(mA), "vL": col(vL), "vU": col(vU)}, do_compression=True)
+
+
+def LoadQpModel(fileName: str):
+    """Read a ``QpModel.mat`` written by SaveQpModel, by the reference's MATLAB script or by MAT.jl."""
+    import scipy.io as sio
+    d = sio.loadmat(fileName)
+    vec = lambda k: np.asarray(d[k], dtype=np.float64).reshape(-1)
+    mat = lambda k: sp.csc_matrix(d[k]) if sp.issparse(d[k]) else np.asarray(d[k], dtype=np.float64)
+    return mat("mP"), vec("vQ"), mat("mA"), vec("vL"), vec("vU")

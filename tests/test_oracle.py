@@ -172,3 +172,20 @@ def test_generator_shapes_and_quirks():
     a = GenerateRandomQP(ProblemClass.randomQp, 30, seed=1234)
     b = GenerateRandomQP(ProblemClass.randomQp, 30, seed=1234)
     assert (a[0] != b[0]).nnz == 0 and np.array_equal(a[1], b[1])   # seed 1234 is reproducible
+
+
+def test_qpmodel_mat_round_trip(tmp_path, c_oracle):
+    """QpModel.mat (keys mP, vQ, mA, vL, vU: SolveQuadraticProgramUnitTest.jl:49-54) round-trips bit-exactly, +-Inf bounds
+    and sparsity included, and the reloaded problem gives the same run."""
+    from quadraticprogramsolver_amd.generator import LoadQpModel, SaveQpModel
+    for pc, dense in ((ProblemClass.lassoOptimization, False), (ProblemClass.randomQp, True)):
+        P, q, A, l, u = GenerateRandomQP(pc, 6, rng=make_rng(2, 2), dense=dense, densityFctr=1.0 if dense else None)
+        f = str(tmp_path / "QpModel.mat")
+        SaveQpModel(f, P, q, A, l, u)
+        P2, q2, A2, l2, u2 = LoadQpModel(f)
+        dn = lambda M: M.toarray() if hasattr(M, "toarray") else M
+        assert np.array_equal(dn(P), dn(P2)) and np.array_equal(dn(A), dn(A2))
+        assert np.array_equal(q, q2) and np.array_equal(l, l2) and np.array_equal(u, u2)
+        x1, i1 = c_oracle.solve(P, q, A, l, u, numIterations=50, epsAbs=0.0, epsRel=0.0)
+        x2, i2 = c_oracle.solve(P2, q2, A2, l2, u2, numIterations=50, epsAbs=0.0, epsRel=0.0)
+        assert np.array_equal(x1, x2)
