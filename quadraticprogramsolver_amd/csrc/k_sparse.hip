@@ -8,7 +8,8 @@
 //
 // Storage: A twice as CSR (rows of A for A w; rows of A' -- which *is* the caller's CSC of A, taken over unchanged apart
 // from Int64 -> int32 and the index base -- for A' v) and P as CSR (symmetric, so its CSC is its CSR).  fp values,
-// int32 indices.  One sub-wave of LPR lanes walks a row with unit stride over (col, val) pairs (coalesced), x is gathered.
+// int32 indices.  CSR-stream SpMV: a workgroup streams one contiguous slice of (col, val) pairs with unit-stride loads;
+// x is gathered (measured: at ~50 nnz/row the kernel is bound by the gather rate of x, not by the CSR streams).
 // CG scalars (alpha, beta, residual, done flag) live in device memory: the host enqueues CG iterations in batches and
 // reads 32 bytes per batch; iterations enqueued past convergence return at their first instruction.
 #include <algorithm>
@@ -20,12 +21,9 @@ namespace qps {
 
 namespace {
 
-struct CgState { double res2, prev2, tol, uc; int iters, done, maxiter, pad; };
+struct CgState { double res2, prev2, tol, uc; int iters, done, maxiter, pad; };   // two copies, ping-ponged per CG iteration
+constexpr int STREAM_NNZ = 1024;   // non-zeros streamed per workgroup (256 threads x 4)
 
-template <typename T> __device__ __forceinline__ T sub_sum(T v, int lpr) {
-    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ double block_sum_256(double v, double* sh) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -36,55 +34,62 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     return r;
 }
 
-// out[row] = a * sum_k val[k] x[col[k]] + b0 v0[row] + b1 v1[row]
-template <typename T, int LPR>
-__global__ __launch_bounds__(256) void k_spmv(int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
-                                              const T* __restrict__ va, const T* __restrict__ x, T* __restrict__ out, T a,
-                                              const T* __restrict__ v0, T b0, const T* __restrict__ v1, T b1,
-                                              const CgState* __restrict__ st) {
+// CSR-stream SpMV: a workgroup owns the consecutive rows [rb[b], rb[b+1]) whose non-zeros (<= STREAM_NNZ) form ONE contiguous
+// slice of (col, val): the slice is read with unit-stride coalesced loads, 4 gathers of x in flight per thread, products go
+// to LDS, then 8 lanes per row sum that row's segment.  A row longer than STREAM_NNZ gets a workgroup of its own (strided
+// walk + block reduction).  out[row] = a * (M x)[row] + b0 v0[row] + b1 v1[row]; optional partial[b] = sum_rows dotv[row] * out[row].
+template <typename T>
+__global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ rb, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                     const T* __restrict__ va, const T* __restrict__ x, T* __restrict__ out, T a,
+                                                     const T* __restrict__ v0, T b0, const T* __restrict__ v1, T b1,
+                                                     const T* __restrict__ dotv, double* __restrict__ partial,
+                                                     const CgState* __restrict__ st) {
     if (st && st->done) return;
-    const int row = (blockIdx.x * 256 + threadIdx.x) / LPR, lane = threadIdx.x % LPR;
-    T s = T(0);
-    if (row < nrows) {
-        const int e = rp[row + 1];
-        for (int k = rp[row] + lane; k < e; k += LPR) s += va[k] * x[ci[k]];
-    }
-    s = sub_sum(s, LPR);
-    if (lane == 0 && row < nrows) {
-        T r = a * s;
-        if (v0) r += b0 * v0[row];
-        if (v1) r += b1 * v1[row];
-        out[row] = r;
-    }
-}
-
-// c = P u + rho A'(tm) + sigma u  (tm = A u), plus this block's share of dot(u, c)   LinearSystemSolvers.jl:152-157
-template <typename T, int LPR>
-__global__ __launch_bounds__(256) void k_op_reduced(int n, const int* __restrict__ Prp, const int* __restrict__ Pci,
-                                                    const T* __restrict__ Pva, const int* __restrict__ Arp,
-                                                    const int* __restrict__ Aci, const T* __restrict__ Ava,
-                                                    const T* __restrict__ u, const T* __restrict__ tm, T rho, T sigma,
-                                                    T* __restrict__ c, double* __restrict__ partial, const CgState* __restrict__ st) {
-    if (st && st->done) return;
+    __shared__ T prod[STREAM_NNZ];
     __shared__ double sh[4];
-    const int row = (blockIdx.x * 256 + threadIdx.x) / LPR, lane = threadIdx.x % LPR;
-    T s = T(0), s2 = T(0);
-    if (row < n) {
-        int e = Prp[row + 1];
-        for (int k = Prp[row] + lane; k < e; k += LPR) s += Pva[k] * u[Pci[k]];
-        e = Arp[row + 1];
-        for (int k = Arp[row] + lane; k < e; k += LPR) s2 += Ava[k] * tm[Aci[k]];
+    const int tid = threadIdx.x;
+    const int r0 = rb[blockIdx.x], r1 = rb[blockIdx.x + 1];
+    const int base = rp[r0], end = rp[r1];
+    double dot = 0.0;
+    if (r1 - r0 == 1 && end - base > STREAM_NNZ) {           // one long row
+        T s = T(0);
+        for (int k = base + tid; k < end; k += 256) s += va[k] * x[ci[k]];
+        const double tot = block_sum_256((double)s, sh);
+        if (tid == 0) {
+            T r = a * (T)tot;
+            if (v0) r += b0 * v0[r0];
+            if (v1) r += b1 * v1[r0];
+            out[r0] = r;
+            if (dotv) dot = (double)dotv[r0] * (double)r;
+        }
+    } else {
+        T p[4]; int c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = base + tid + 256 * j; c[j] = (k < end) ? ci[k] : -1; p[j] = (k < end) ? va[k] : T(0); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c[j] >= 0) p[j] *= x[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prod[tid + 256 * j] = p[j];
+        __syncthreads();
+        const int lane = tid & 7;
+        for (int row = r0 + (tid >> 3); row < r1; row += 32) {
+            const int s0 = rp[row] - base, s1 = rp[row + 1] - base;
+            T s = T(0);
+            for (int k = s0 + lane; k < s1; k += 8) s += prod[k];
+            s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+            if (lane == 0) {
+                T r = a * s;
+                if (v0) r += b0 * v0[row];
+                if (v1) r += b1 * v1[row];
+                out[row] = r;
+                if (dotv) dot += (double)dotv[row] * (double)r;
+            }
+        }
     }
-    s = sub_sum(s, LPR); s2 = sub_sum(s2, LPR);
-    double d = 0.0;
-    if (lane == 0 && row < n) {
-        const T ui = u[row];
-        const T ci = s + rho * s2 + sigma * ui;
-        c[row] = ci;
-        d = (double)ui * (double)ci;
+    if (partial) {
+        const double tot = block_sum_256(dot, sh);
+        if (tid == 0) partial[blockIdx.x] = tot;
     }
-    d = block_sum_256(d, sh);
-    if (partial && threadIdx.x == 0) partial[blockIdx.x] = d;
 }
 
 // r = b - c, u = 0, partial ||r||^2
@@ -110,14 +115,6 @@ __global__ __launch_bounds__(256) void k_cg_init_final(int nparts, const double*
         st->iters = 0; st->maxiter = maxiter;
         st->done = (!(residual <= st->tol) && 0 < maxiter) ? 0 : 1;
     }
-}
-// u = r + beta u, beta = res2 / prev2
-template <typename T>
-__global__ __launch_bounds__(256) void k_cg_update_u(int n, const T* __restrict__ r, T* __restrict__ u, const CgState* __restrict__ st) {
-    if (st->done) return;
-    const T beta = (T)(st->res2 / st->prev2);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) u[i] = r[i] + beta * u[i];
 }
 // alpha = res2 / dot(u, c); x += alpha u; r -= alpha c; partial ||r||^2
 template <typename T>
@@ -153,13 +150,37 @@ __global__ __launch_bounds__(256) void k_cg_finish(int nparts, const double* __r
         if (residual <= st->tol || st->iters >= st->maxiter) st->done = 1;
     }
 }
+// Merged "finish previous iteration + start this one": every block reduces the ||r||^2 partials of the previous
+// iteration in the same order (same value in every block), block 0 publishes the new scalars into the OTHER state slot
+// (nobody reads that slot during this launch), then u = r + beta u with beta = res2_new / res2_old.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_next_u(int n, int nparts, const double* __restrict__ partial_rr, const T* __restrict__ r,
+                                                   T* __restrict__ u, const CgState* __restrict__ cur, CgState* __restrict__ nxt, int first) {
+    __shared__ double sh[4];
+    if (cur->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = *cur; return; }
+    double res2 = cur->res2, prev2 = cur->prev2; int iters = cur->iters, done = 0;
+    if (!first) {
+        double d = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 256) d += partial_rr[i];
+        d = block_sum_256(d, sh);
+        prev2 = res2; res2 = d; iters += 1;
+        if (sqrt(d) <= cur->tol || iters >= cur->maxiter) done = 1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CgState s = *cur; s.res2 = res2; s.prev2 = prev2; s.iters = iters; s.done = done; *nxt = s;
+    }
+    if (done) return;
+    const T beta = (T)(res2 / prev2);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) u[i] = r[i] + beta * u[i];
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_axpby(int n, T a, const T* __restrict__ x, T b, const T* __restrict__ y, T* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = a * x[i] + b * y[i];
 }
 
-struct Csr { int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int lpr = 16; };
+struct Csr { int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int lpr = 16; int* rb = nullptr; int nblocks = 0; };
 
 int pick_lpr(int64_t nnz, int nrows) {
     const double avg = nrows > 0 ? (double)nnz / nrows : 0.0;
@@ -183,6 +204,18 @@ template <typename T> struct SparseSolver : SolverBase {
         M.nrows = nrows; M.nnz = (int64_t)ci.size(); M.lpr = pick_lpr(M.nnz, nrows);
         M.rp = dalloc<int>(nrows + 1); M.ci = dalloc<int>(M.nnz); M.va = dalloc<T>(M.nnz);
         HIPC(hipMemcpy(M.rp, rp.data(), sizeof(int) * (nrows + 1), hipMemcpyHostToDevice));
+        {   // row blocks of the CSR-stream kernel: consecutive rows with <= STREAM_NNZ non-zeros; a longer row stands alone
+            std::vector<int> rbv(1, 0);
+            int start = 0;
+            for (int r = 0; r < nrows; ++r) {
+                if (rp[r + 1] - rp[start] > STREAM_NNZ && r > start) { rbv.push_back(r); start = r; }
+                if (rp[r + 1] - rp[start] > STREAM_NNZ) { rbv.push_back(r + 1); start = r + 1; }   // single long row
+            }
+            if (start < nrows) rbv.push_back(nrows);
+            M.nblocks = (int)rbv.size() - 1;
+            M.rb = dalloc<int>((int64_t)rbv.size());
+            HIPC(hipMemcpy(M.rb, rbv.data(), sizeof(int) * rbv.size(), hipMemcpyHostToDevice));
+        }
         if (M.nnz > 0) {
             HIPC(hipMemcpy(M.ci, ci.data(), sizeof(int) * M.nnz, hipMemcpyHostToDevice));
             std::vector<T> v(va.begin(), va.end());
@@ -231,9 +264,7 @@ template <typename T> struct SparseSolver : SolverBase {
         l = dalloc<T>(mm); u = dalloc<T>(mm); z = dalloc<T>(mm); zp = dalloc<T>(mm); y = dalloc<T>(mm); zz = dalloc<T>(mm);
         w = dalloc<T>(mm); tm = dalloc<T>(mm); Ax = dalloc<T>(mm);
         nb_n = (int)((n + 255) / 256);
-        const int lpr_op = std::max(P.lpr, At.lpr); P.lpr = At.lpr = lpr_op;
-        nb_op = (int)((n * lpr_op + 255) / 256);
-        part_uc = dalloc<double>(nb_op + 64); part_rr = dalloc<double>(nb_n + 64);
+        part_uc = dalloc<double>(std::max(At.nblocks, P.nblocks) + 64); part_rr = dalloc<double>(nb_n + 64);
         state = reinterpret_cast<CgState*>(dalloc<double>(16));
         HIPC(hipHostMalloc((void**)&state_host, sizeof(CgState)));
         scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
@@ -250,7 +281,7 @@ template <typename T> struct SparseSolver : SolverBase {
     ~SparseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
-        void* ptrs[] = {A.rp, A.ci, A.va, At.rp, At.ci, At.va, P.rp, P.ci, P.va, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
+        void* ptrs[] = {A.rp, A.ci, A.va, A.rb, At.rp, At.ci, At.va, At.rb, P.rp, P.ci, P.va, P.rb, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
                         Ax, Px, Aty, part_uc, part_rr, state, scratch, res_dev, stage};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (res_host) (void)hipHostFree(res_host);
@@ -258,41 +289,42 @@ template <typename T> struct SparseSolver : SolverBase {
         if (st) (void)hipStreamDestroy(st);
     }
 
-    void spmv(const Csr& M, const T* xin, T* out, T a, const T* v0, T b0, const T* v1, T b1, const CgState* stt) {
-        if (M.nrows <= 0) return;
-        const int grid = (int)(((int64_t)M.nrows * M.lpr + 255) / 256);
-        const T* va = static_cast<const T*>(M.va);
-#define QPS_SP(L) hipLaunchKernelGGL((k_spmv<T, L>), dim3(grid), dim3(256), 0, st, M.nrows, M.rp, M.ci, va, xin, out, a, v0, b0, v1, b1, stt)
-        switch (M.lpr) { case 4: QPS_SP(4); break; case 8: QPS_SP(8); break; case 16: QPS_SP(16); break; case 32: QPS_SP(32); break; default: QPS_SP(64); }
-#undef QPS_SP
+    void spmv(const Csr& M, const T* xin, T* out, T a, const T* v0, T b0, const T* v1, T b1, const CgState* stt,
+              const T* dotv = nullptr, double* partial = nullptr) {
+        if (M.nblocks <= 0) return;
+        hipLaunchKernelGGL((k_spmv_stream<T>), dim3(M.nblocks), dim3(256), 0, st, M.rb, M.rp, M.ci, static_cast<const T*>(M.va), xin, out, a,
+                           v0, b0, v1, b1, dotv, partial, stt);
     }
-    // c = Op(uin) with tm = A uin; optional partial dot(uin, c)
+    // c = P u + rho A'(A u) + sigma u (LinearSystemSolvers.jl:152-157) as three streamed SpMVs; optional partials of dot(u, c)
     void op_reduced(const T* uin, T* cout, double rho, double sigma, double* partial, const CgState* stt) {
-        if (m > 0) spmv(A, uin, tm, T(1), nullptr, T(0), nullptr, T(0), stt);
-        const T* pv = static_cast<const T*>(P.va); const T* av = static_cast<const T*>(At.va);
-#define QPS_OP(L) hipLaunchKernelGGL((k_op_reduced<T, L>), dim3(nb_op), dim3(256), 0, st, (int)n, P.rp, P.ci, pv, At.rp, At.ci, av, uin, tm, (T)rho, (T)sigma, cout, partial, stt)
-        switch (P.lpr) { case 4: QPS_OP(4); break; case 8: QPS_OP(8); break; case 16: QPS_OP(16); break; case 32: QPS_OP(32); break; default: QPS_OP(64); }
-#undef QPS_OP
+        spmv(P, uin, cout, T(1), uin, (T)sigma, nullptr, T(0), stt, (m > 0) ? nullptr : uin, (m > 0) ? nullptr : partial);
+        if (m > 0) {
+            spmv(A, uin, tm, T(1), nullptr, T(0), nullptr, T(0), stt);
+            spmv(At, tm, cout, (T)rho, cout, T(1), nullptr, T(0), stt, uin, partial);
+        }
     }
+    int op_parts() const { return m > 0 ? At.nblocks : P.nblocks; }
 
     // IterativeSolvers.cg!(xx, Op, tt; abstol = eps_pcg, maxiter = itr_pcg), xx warm started
     int cg(double rho, double sigma) {
+        CgState* slot[2] = {state, state + 1};
+        int cur = 0;
         op_reduced(xx, cc, rho, sigma, nullptr, nullptr);
         hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_n), dim3(256), 0, st, (int)n, tt, cc, cr, cu, part_rr);
-        hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, state, eps_pcg, itr_pcg);
+        hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur], eps_pcg, itr_pcg);
         int launched = 0, batch = std::max(1, std::min(last_cg + 1, 64));
         for (;;) {
-            {
-                for (int b = 0; b < batch; ++b) {
-                    ProfScope ps(prof, cat_op, 2);
-                    hipLaunchKernelGGL((k_cg_update_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, cr, cu, state);
-                    op_reduced(cu, cc, rho, sigma, part_uc, state);
-                    hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_op, part_uc, cu, cc, xx, cr, part_rr, state);
-                    hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, nb_n, part_rr, state);
-                }
+            for (int b = 0; b < batch; ++b) {
+                ProfScope ps(prof, cat_op, 2);
+                // fold the previous iteration's ||r||^2, publish the scalars into the other slot, u = r + beta u
+                hipLaunchKernelGGL((k_cg_next_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_n, part_rr, cr, cu, slot[cur], slot[cur ^ 1], b == 0 ? 1 : 0);
+                cur ^= 1;
+                op_reduced(cu, cc, rho, sigma, part_uc, slot[cur]);
+                hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, op_parts(), part_uc, cu, cc, xx, cr, part_rr, slot[cur]);
             }
+            hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur]);   // fold the last iteration of the batch
             launched += batch;
-            HIPC(hipMemcpyAsync(state_host, state, sizeof(CgState), hipMemcpyDeviceToHost, st));
+            HIPC(hipMemcpyAsync(state_host, slot[cur], sizeof(CgState), hipMemcpyDeviceToHost, st));
             HIPC(hipStreamSynchronize(st));
             prof.harvest();
             if (state_host->done || launched >= itr_pcg) break;
