@@ -28,12 +28,12 @@ template <typename T> struct DenseSolver : SolverBase {
     T *A = nullptr, *P = nullptr, *q = nullptr, *l = nullptr, *u = nullptr;
     T *PI = nullptr, *AA = nullptr, *M = nullptr, *S = nullptr, *tmp = nullptr, *dinv = nullptr; int* fail = nullptr;
     T *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr, *xx = nullptr, *zz = nullptr, *tt = nullptr, *yv = nullptr;
-    T *part = nullptr, *part2 = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
+    T *part = nullptr, *part2 = nullptr, *sw_part = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
     int pass_slabs = 0, pass_rpw = 0;   // fused-pass plan (0 slabs: shape not supported, unfused loop only)
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
     int nb = 2048; int part_tiles = 0;
-    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk;
+    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk, cat_sweep, cat_xsum;
 
     DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
         device = dev; n = n_; m = m_; dtype = dt;
@@ -52,6 +52,7 @@ template <typename T> struct DenseSolver : SolverBase {
         const int slabs = std::max(std::max(part_tiles, pass_slabs), 1);
         part = dalloc<T>((int64_t)slabs * NP);
         part2 = dalloc<T>((int64_t)slabs * NP);
+        sw_part = dalloc<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
         Ax = dalloc<T>(MP); Px = dalloc<T>(NP); Aty = dalloc<T>(NP);
         scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
         HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
@@ -68,11 +69,15 @@ template <typename T> struct DenseSolver : SolverBase {
         // fused pass: A once + x~, x, z, y, l, u in, x, z, y out (s*m*n + vector traffic)
         cat_pass = prof.category("apass(fused A-pass)", s * ((double)m * n + 3.0 * n + 6.0 * m));
         cat_passchk = prof.category("apass(check variant)", s * ((double)m * n + 4.0 * n + 6.0 * m));
+        // fused forward+backward sweep: algorithmic bytes of BOTH sweeps (SURVEY §8d counts n(n+1)/2 per sweep); the kernel
+        // actually reads the triangle once
+        cat_sweep = prof.category("sweeps(fused fwd+bwd)", s * ((double)n * (n + 1) + 4.0 * n));
+        cat_xsum = prof.category("colsum(x~ slabs)", s * ((double)sweep_fused_slabs<T>(NP) * n + n));
     }
     ~DenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
-        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, Ax, Px, Aty, scratch, res_dev, stage};
+        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, sw_part, Ax, Px, Aty, scratch, res_dev, stage};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (res_host) (void)hipHostFree(res_host);
         if (st) (void)hipStreamDestroy(st);
@@ -133,6 +138,20 @@ template <typename T> struct DenseSolver : SolverBase {
     // x~ = (L L')^{-1} tt via the blocked sweeps over S (tt is consumed)
     void sweeps() {
         const int nblk = (NP + nb - 1) / nb;
+        static const bool use_persist = !(getenv("QPS_TRSV_PERSIST") && atoi(getenv("QPS_TRSV_PERSIST")) == 0);
+        static const int sweep_mode = getenv("QPS_SWEEP_MODE") ? atoi(getenv("QPS_SWEEP_MODE")) : 2;
+        if (nblk == 1 && sweep_mode == 2 && trsv_persist_supported<T>(NP)) {
+            // one inverted block: forward and backward sweep read the same entries -> one fused pass over the triangle
+            int G;
+            { ProfScope ps(prof, cat_sweep, 2); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
+            { ProfScope ps(prof, cat_xsum, 2); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
+            return;
+        }
+        if (nblk == 1 && use_persist && sweep_mode == 1 && trsv_persist_supported<T>(NP)) {   // two persistent triangular mat-vecs
+            { ProfScope ps(prof, cat_fwd, 2); trsv_persist<T>(st, S, NP, NP, tt, yv, 1); }
+            { ProfScope ps(prof, cat_bwd, 2); trsv_persist<T>(st, S, NP, NP, yv, xx, 2); }
+            return;
+        }
         {
             ProfScope ps(prof, cat_fwd, 2);
             for (int J = 0; J < nblk; ++J) {
@@ -294,11 +313,11 @@ struct BatchSolverBase {
 
 template <typename T> struct BatchedDenseSolver : BatchSolverBase {
     hipStream_t st = nullptr;
-    int NP = 0, MP = 0, nb = 0, slabs = 0, rpw = 0, part_tiles = 0;
+    int NP = 0, MP = 0, nb = 0, slabs = 0, rpw = 0, part_tiles = 0, sw_slabs = 0;
     T *A = nullptr, *P = nullptr, *q = nullptr, *l = nullptr, *u = nullptr, *PI = nullptr, *AA = nullptr, *M = nullptr, *S = nullptr,
       *tmp = nullptr, *dinv = nullptr;
     T *x = nullptr, *xp = nullptr, *xres = nullptr, *z = nullptr, *y = nullptr, *xx = nullptr, *tt = nullptr, *yv = nullptr, *part = nullptr,
-      *part2 = nullptr, *part_tmp = nullptr, *Px = nullptr, *Aty = nullptr;
+      *part2 = nullptr, *part_tmp = nullptr, *sw_part = nullptr, *Px = nullptr, *Aty = nullptr;
     int* fail = nullptr; int* d_active = nullptr; double *d_rho = nullptr, *d_rhorho = nullptr;
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     int* h_int = nullptr; double* h_dbl = nullptr;   // pinned staging for the small per-QP arrays
@@ -318,6 +337,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         x = dalloc<T>(c * NP); xp = dalloc<T>(c * NP); xres = dalloc<T>(c * NP); xx = dalloc<T>(c * NP); tt = dalloc<T>(c * NP);
         yv = dalloc<T>(c * NP); Px = dalloc<T>(c * NP); Aty = dalloc<T>(c * NP); z = dalloc<T>(c * MP); y = dalloc<T>(c * MP);
         part = dalloc<T>(c * slabs * NP); part2 = dalloc<T>(c * slabs * NP); part_tmp = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
+        sw_slabs = sweep_fused_slabs<T>(NP, count); sw_part = dalloc<T>(c * std::max(sw_slabs, 1) * NP);
         fail = dalloc<int>(count + 4); d_active = dalloc<int>(count + 4); d_rho = dalloc<double>(count + 4); d_rhorho = dalloc<double>(count + 4);
         scratch = dalloc<unsigned long long>(16 * c); res_dev = dalloc<double>(8 * c);
         HIPC(hipHostMalloc((void**)&res_host, 8 * c * sizeof(double)));
@@ -328,7 +348,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
     ~BatchedDenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
-        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, x, xp, xres, z, y, xx, tt, yv, part, part2, part_tmp, Px, Aty, fail, d_active,
+        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, x, xp, xres, z, y, xx, tt, yv, part, part2, part_tmp, sw_part, Px, Aty, fail, d_active,
                         d_rho, d_rhorho, scratch, res_dev, stage};
         for (void* p_ : ptrs) if (p_) (void)hipFree(p_);
         if (res_host) (void)hipHostFree(res_host);
@@ -433,11 +453,18 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             }
             const bool check = (ii % p.numItrConv == 0);
             colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP, bsC);                  // LinearSystemSolvers.jl:136
+            if (nblk == 1 && trsv_persist_supported<T>(NP)) {                                       // both sweeps in one pass
+                BatchStride bsW = bsS; bsW.vout = (int64_t)sw_slabs * NP;
+                sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP, bsW);
+                BatchStride bsX = bsS; bsX.mat = (int64_t)sw_slabs * NP;
+                colsum<T>(st, sw_part, NP, sw_slabs, nullptr, T(0), nullptr, T(0), xx, NP, bsX);
+            } else
             for (int J = 0; J < nblk; ++J) {                                                        // forward sweep
                 const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
                 gemv_rows<T>(st, S, NP, tt, yv, nullptr, T(1), T(0), r0, r1, r0, r1, 1, bsS);
                 if (r1 < NP) gemv_rows<T>(st, S, NP, yv, tt, tt, T(-1), T(1), r1, NP, r0, r1, 0, bsS);
             }
+            if (!(nblk == 1 && trsv_persist_supported<T>(NP)))
             for (int J = nblk - 1; J >= 0; --J) {                                                   // backward sweep
                 const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
                 gemv_rows<T>(st, S, NP, yv, xx, nullptr, T(1), T(0), r0, r1, r0, r1, 2, bsS);
