@@ -52,8 +52,14 @@ __global__ __launch_bounds__(THREADS) void k_gemv_rows(const T* __restrict__ S, 
         const T* vp = reinterpret_cast<const T*>(&vv);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const V a = *reinterpret_cast<const V*>(Srow + (int64_t)i * ld + c);
-            const T* ap = reinterpret_cast<const T*>(&a);
+            // TRI == 0 streams A or P once (non-temporal: keep the sweep triangle and the slabs cached); TRI != 0 reads the
+            // sweep matrix, which is re-read every iteration and should stay cached
+            typedef T NV __attribute__((ext_vector_type(VN)));
+            const NV* src = reinterpret_cast<const NV*>(Srow + (int64_t)i * ld + c);
+            const NV a = (TRI == 0) ? __builtin_nontemporal_load(src) : *src;
+            T ap[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) ap[e] = a[e];
 #pragma unroll
             for (int e = 0; e < VN; ++e) {
                 bool ok = true;
@@ -105,10 +111,10 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const T* __restrict__ S, int6
     for (int i = 0; i < GC_RT; ++i) {
         T w = ca * va[rbase + i];
         if (vb) w += cb * vb[rbase + i];
-        const V a = *reinterpret_cast<const V*>(Sp + (int64_t)i * ld);
-        const T* ap = reinterpret_cast<const T*>(&a);
+        typedef T NV __attribute__((ext_vector_type(VN)));
+        const NV a = __builtin_nontemporal_load(reinterpret_cast<const NV*>(Sp + (int64_t)i * ld));   // A streamed once
 #pragma unroll
-        for (int e = 0; e < VN; ++e) acc[e] += ap[e] * w;
+        for (int e = 0; e < VN; ++e) acc[e] += a[e] * w;
     }
     V o;
     T* op = reinterpret_cast<T*>(&o);
