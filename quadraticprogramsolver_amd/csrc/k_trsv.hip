@@ -1,11 +1,6 @@
-// k_trsv.hip -- persistent, software-pipelined triangular matrix-vector kernel for the case where one inverted diagonal
-// block covers the whole factor (nb >= n): each sweep is out = tri(S) * v with tri = "c <= r" (forward, S lower = inv(L))
-// or "c >= r" (backward, S upper = inv(L)').  Same bytes as a substitution sweep (n(n+1)/2 elements), no dependency chain.
-//
-// Why a second kernel next to k_gemv_rows: the triangular rows have lengths 1..n, and a launch of one short-lived
-// workgroup per row pair runs at ~4.1 TB/s.  Here 256 persistent workgroups (one per CU) each walk row pairs
-// g, g + 256, g + 512, ... (cyclic => every workgroup gets the same mix of short and long rows), with the next pair's loads in
-// flight while the current pair is reduced -- the structure that brings the fused A-pass to 5.5 TB/s.
+// k_trsv.hip -- the triangular solve for the case where one inverted diagonal block covers the whole factor (nb >= n):
+// both sweeps of x~ = L'^{-1} (L^{-1} t) in one pass over W = inv(L).  (A persistent, software-pipelined kernel per
+// *separate* sweep was measured and dropped: 17-20 us per sweep against 18.8 us for the plain row-dot launch.)
 #include <cstdlib>
 
 #include "qps_kernels.h"
@@ -19,89 +14,6 @@ template <typename T> __device__ __forceinline__ T wsum(T v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-
-template <typename T, int THREADS, int KC, int RB, int TRI>
-__global__ __launch_bounds__(THREADS) void k_trsv_persist(const T* __restrict__ S, int64_t ld, int NP, const T* __restrict__ v,
-                                                          T* __restrict__ out, BatchStride bs) {
-    using V = typename VecOf<T>::type;
-    constexpr int VN = VecOf<T>::N, CHUNK = THREADS * VN, WAVES = THREADS / 64;
-    if (bs.active && !bs.active[blockIdx.y]) return;
-    S += (int64_t)blockIdx.y * bs.mat; v += (int64_t)blockIdx.y * bs.vin; out += (int64_t)blockIdx.y * bs.vout;
-    const int tid = threadIdx.x, G = gridDim.x, g = blockIdx.x;
-    const int ntiles = NP / RB;
-    __shared__ T red[2][WAVES][RB];
-
-    V xv[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-        const int c = tid * VN + k * CHUNK;
-        if (c < NP) xv[k] = *reinterpret_cast<const V*>(v + c);
-        else { T* p = reinterpret_cast<T*>(&xv[k]);
-#pragma unroll
-            for (int e = 0; e < VN; ++e) p[e] = T(0); }
-    }
-    // tile t covers rows [t*RB, t*RB + RB); forward sweeps take the long (bottom) rows first, backward the long (top) rows first
-    auto tile_row = [&](int it) { const int t = g + it * G; return (TRI == 1 ? (ntiles - 1 - t) : t) * RB; };
-    auto load = [&](V (&a)[RB][KC], int row) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                const int c = tid * VN + k * CHUNK;
-                // skip 16-byte pieces that lie entirely outside the triangle (they would be multiplied by zero)
-                const bool need = (c < NP) && (TRI == 1 ? (c <= row + i) : (c + VN - 1 >= row + i));
-                if (need) a[i][k] = *reinterpret_cast<const V*>(S + (int64_t)(row + i) * ld + c);
-                else { T* p = reinterpret_cast<T*>(&a[i][k]);
-#pragma unroll
-                    for (int e = 0; e < VN; ++e) p[e] = T(0); }
-            }
-    };
-    auto process = [&](V (&a)[RB][KC], int row, int par) {
-        T d[RB];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                const int c = tid * VN + k * CHUNK;
-                const T* ap = reinterpret_cast<const T*>(&a[i][k]);
-                const T* xp = reinterpret_cast<const T*>(&xv[k]);
-#pragma unroll
-                for (int e = 0; e < VN; ++e) {
-                    const bool ok = (TRI == 1) ? (c + e <= row + i) : (c + e >= row + i);
-                    s += ok ? ap[e] * xp[e] : T(0);
-                }
-            }
-            d[i] = wsum(s);
-        }
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i) red[par][tid >> 6][i] = d[i];
-        }
-        __syncthreads();   // one barrier per tile: red[] is double-buffered by tile parity
-        if (tid < RB) {
-            T s = T(0);
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) s += red[par][w][tid];   // fixed order
-            out[row + tid] = s;
-        }
-    };
-
-    const int my_tiles = (ntiles - g + G - 1) / G;   // tiles g, g+G, ... < ntiles
-    if (my_tiles <= 0) return;
-    V bufA[RB][KC], bufB[RB][KC];
-    load(bufA, tile_row(0));
-    for (int it = 0; it < my_tiles; it += 2) {
-        const bool haveB = it + 1 < my_tiles;
-        if (haveB) load(bufB, tile_row(it + 1));
-        process(bufA, tile_row(it), 0);
-        if (haveB) {
-            if (it + 2 < my_tiles) load(bufA, tile_row(it + 2));
-            process(bufB, tile_row(it + 1), 1);
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Both sweeps in ONE pass over the lower triangle (nb >= n, S lower = W = inv(L)):
@@ -208,25 +120,9 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
 
 }  // namespace
 
-template <typename T> bool trsv_persist_supported(int NP) { return NP <= 8 * 512 * VecOf<T>::N && NP >= 1024; }
+template <typename T> bool sweep_fused_supported(int NP) { return NP <= 8 * 512 * VecOf<T>::N && NP >= 1024; }
 
-template <typename T>
-void trsv_persist(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* out, int tri, BatchStride bs) {
-    constexpr int TH = 512, RB = 2 * (VecOf<T>::N / 2 == 0 ? 1 : VecOf<T>::N / 2);   // 2 rows (fp64) / 4 rows (fp32): multiples of the vector width
-    const int chunk = TH * VecOf<T>::N;
-    const int kc = (NP + chunk - 1) / chunk;
-    const int ntiles = NP / RB;
-    static const int total = [] { const char* e = getenv("QPS_TRSV_WGS"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
-    const int per = bs.count >= total ? 1 : total / bs.count;
-    dim3 grid(ntiles < per ? ntiles : per, bs.count);
-#define QPS_T(KC, TRI) hipLaunchKernelGGL((k_trsv_persist<T, TH, KC, RB, TRI>), grid, dim3(TH), 0, st, S, ld, NP, v, out, bs)
-#define QPS_TK(KC) do { if (tri == 1) QPS_T(KC, 1); else QPS_T(KC, 2); } while (0)
-    if (kc <= 1) QPS_TK(1); else if (kc <= 2) QPS_TK(2); else if (kc <= 4) QPS_TK(4); else QPS_TK(8);
-#undef QPS_TK
-#undef QPS_T
-}
-
-static int sweep_rb() { static int rb = [] { const char* e = getenv("QPS_SWEEP_RB"); return e ? atoi(e) : 4; }(); return rb; }
+static int sweep_rb() { static int rb = [] { const char* e = getenv("QPS_SWEEP_RB"); return e ? atoi(e) : 2; }(); return rb; }   // fp64: 2-row tiles measured best
 
 template <typename T> int sweep_fused_slabs(int NP, int count) {
     const int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
@@ -255,8 +151,7 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
 #define INST(T)                                                     \
     template int sweep_fused_slabs<T>(int, int);                    \
     template int sweep_fused<T>(hipStream_t, const T*, int64_t, int, const T*, T*, int64_t, BatchStride); \
-    template bool trsv_persist_supported<T>(int);                   \
-    template void trsv_persist<T>(hipStream_t, const T*, int64_t, int, const T*, T*, int, BatchStride);
+    template bool sweep_fused_supported<T>(int);
 INST(double)
 INST(float)
 #undef INST

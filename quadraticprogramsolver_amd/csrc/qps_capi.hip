@@ -138,18 +138,12 @@ template <typename T> struct DenseSolver : SolverBase {
     // x~ = (L L')^{-1} tt via the blocked sweeps over S (tt is consumed)
     void sweeps() {
         const int nblk = (NP + nb - 1) / nb;
-        static const bool use_persist = !(getenv("QPS_TRSV_PERSIST") && atoi(getenv("QPS_TRSV_PERSIST")) == 0);
         static const int sweep_mode = getenv("QPS_SWEEP_MODE") ? atoi(getenv("QPS_SWEEP_MODE")) : 2;
-        if (nblk == 1 && sweep_mode == 2 && trsv_persist_supported<T>(NP)) {
+        if (nblk == 1 && sweep_mode == 2 && sweep_fused_supported<T>(NP)) {
             // one inverted block: forward and backward sweep read the same entries -> one fused pass over the triangle
             int G;
             { ProfScope ps(prof, cat_sweep, 2); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
             { ProfScope ps(prof, cat_xsum, 2); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
-            return;
-        }
-        if (nblk == 1 && use_persist && sweep_mode == 1 && trsv_persist_supported<T>(NP)) {   // two persistent triangular mat-vecs
-            { ProfScope ps(prof, cat_fwd, 2); trsv_persist<T>(st, S, NP, NP, tt, yv, 1); }
-            { ProfScope ps(prof, cat_bwd, 2); trsv_persist<T>(st, S, NP, NP, yv, xx, 2); }
             return;
         }
         {
@@ -453,7 +447,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             }
             const bool check = (ii % p.numItrConv == 0);
             colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP, bsC);                  // LinearSystemSolvers.jl:136
-            if (nblk == 1 && trsv_persist_supported<T>(NP)) {                                       // both sweeps in one pass
+            if (nblk == 1 && sweep_fused_supported<T>(NP)) {                                       // both sweeps in one pass
                 BatchStride bsW = bsS; bsW.vout = (int64_t)sw_slabs * NP;
                 sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP, bsW);
                 BatchStride bsX = bsS; bsX.mat = (int64_t)sw_slabs * NP;
@@ -464,7 +458,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 gemv_rows<T>(st, S, NP, tt, yv, nullptr, T(1), T(0), r0, r1, r0, r1, 1, bsS);
                 if (r1 < NP) gemv_rows<T>(st, S, NP, yv, tt, tt, T(-1), T(1), r1, NP, r0, r1, 0, bsS);
             }
-            if (!(nblk == 1 && trsv_persist_supported<T>(NP)))
+            if (!(nblk == 1 && sweep_fused_supported<T>(NP)))
             for (int J = nblk - 1; J >= 0; --J) {                                                   // backward sweep
                 const int r0 = J * nb, r1 = std::min(NP, r0 + nb);
                 gemv_rows<T>(st, S, NP, yv, xx, nullptr, T(1), T(0), r0, r1, r0, r1, 2, bsS);

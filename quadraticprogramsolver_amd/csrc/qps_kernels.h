@@ -68,13 +68,10 @@ void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, c
            T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots,
            PassBatch pb = PassBatch());
 
-// ---- persistent triangular matrix-vector kernel (k_trsv.hip): out = tri(S) v over all NP rows (single-block sweeps) -----
-template <typename T> bool trsv_persist_supported(int NP);
-template <typename T>
-void trsv_persist(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* out, int tri, BatchStride bs = BatchStride());
-
+// ---- fused triangular sweeps (k_trsv.hip) -----------------------------------------------------------------------------
+template <typename T> bool sweep_fused_supported(int NP);
 // Both sweeps fused into one pass over the lower triangle (single inverted block): slabs of x~ = W' (W t); the caller adds
-// the slabs with colsum().  bs.mat / bs.vin as for trsv_persist, bs.vout = stride between the slab sets of two QPs.
+// the slabs with colsum().  bs.mat = stride between sweep matrices, bs.vin = stride of t, bs.vout = stride between the slab sets of two QPs.
 template <typename T> int sweep_fused_slabs(int NP, int count = 1);
 template <typename T>
 int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* part, int64_t part_ld, BatchStride bs = BatchStride());
