@@ -310,3 +310,47 @@ def test_cg_plugin_pair_in_isolation(gpu, c_oracle):
             assert np.linalg.norm(M @ xx - rhs) <= 1.1 * tol
             assert np.abs(zz - Ad @ xx).max() <= 1e-10 * max(1.0, np.abs(zz).max())
             x0 = xx.copy()
+
+
+def test_run_benchmarks_driver(gpu, tmp_path):
+    """RunBenchmarks.jl counterpart: 9 classes x 2 sizes x sims -> one CSV row; a second run appends under the same header;
+    a different layout is refused (RunBenchmarks.jl:125-137)."""
+    import csv
+    from quadraticprogramsolver_amd import run_benchmarks
+    f = str(tmp_path / "QPSBenchmark.csv")
+    header, row = run_benchmarks.run(f, sizes=(2, 20), num_simulations=1, samples=2)
+    assert len(header) == len(row) == 4 + 4 * 9 * 2
+    run_benchmarks.run(f, sizes=(2, 20), num_simulations=1, samples=2)
+    rows = list(csv.reader(open(f)))
+    assert len(rows) == 3 and rows[0] == header
+    conv = [rows[1][i] for i in range(7, len(header), 4)]
+    assert conv.count("True") >= 12          # tiny random instances may be infeasible; most converge
+    with pytest.raises(RuntimeError):
+        run_benchmarks.run(f, sizes=(2,), num_simulations=1, samples=1)
+
+
+def test_large_n_falls_back_to_unfused_kernels(gpu):
+    """n beyond the register-tile limit of the fused kernels (NP > 8192 in fp64): unfused loop, three sweep blocks with a
+    ragged last one.  Checked through size-independent properties (linear-solve residual, reported residuals)."""
+    n, m = 9000, 3000
+    rng = make_rng(31, 0)
+    d = rng.random(n) + 0.5
+    U = rng.standard_normal((n, 8)) / np.sqrt(n)
+    P = np.diag(d) + U @ U.T                       # SPD, cheap to build and to multiply
+    A = rng.standard_normal((m, n)) / np.sqrt(n)
+    q = rng.standard_normal(n); l = -rng.random(m); u = rng.random(m)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        rho, sigma = 0.5, 1e-6
+        prob.linsys_init(rho, sigma)
+        x, z, y = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(m)
+        xx, zz = np.zeros(n), np.zeros(m)
+        prob.linsys_solve(x, z, y, rho, sigma, False, xx, zz)
+        rhs = sigma * x - q + A.T @ (rho * z - y)
+        lhs = P @ xx + sigma * xx + rho * (A.T @ (A @ xx))
+        assert np.abs(lhs - rhs).max() <= 1e-10 * max(1.0, np.abs(rhs).max())
+        xk = np.zeros(n); info = {}
+        flag = prob.solve(xk, numIterations=2000, ϵAbs=1e-6, ϵRel=1e-6, ρ=rho, adptΡ=True, info=info)
+        zk, yk = prob.dual()
+        assert int(flag) == 3
+        assert abs(info["resPrim"] - np.abs(A @ xk - zk).max()) <= 1e-9 and abs(info["resDual"] - np.abs(P @ xk + q + A.T @ yk).max()) <= 1e-8
+        assert np.all(zk >= l - 1e-12) and np.all(zk <= u + 1e-12)
