@@ -253,7 +253,12 @@ template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg, int count
     if (NP > apass_max_np<T>() || MP <= 0) { *rows_per_wg = 0; return 0; }
     const int R = 4;
     // about one workgroup per CU over the whole launch (256 CUs), split evenly over the QPs of a batch
-    const int target = count >= 256 ? 1 : 256 / (count < 1 ? 1 : count);
+    // One workgroup per CU when the register tile is large (KC >= 2: 138+ VGPRs, one 8-wave workgroup fits per CU); narrow
+    // problems (KC == 1, <= 98 VGPRs) take four per CU (measured on 256 x n=1024: 164 k -> 213 k QP-iterations/s)
+    static const int total_env = [] { const char* e = getenv("QPS_PASS_WGS"); return e ? atoi(e) : 0; }();
+    const int kc1 = NP <= pass_threads() * VecOf<T>::N;
+    const int total = total_env > 0 ? total_env : (kc1 ? 1024 : 256);
+    const int target = count >= total ? 1 : total / (count < 1 ? 1 : count);
     int rpw = (MP + target - 1) / target;
     rpw = ((rpw + R - 1) / R) * R;
     *rows_per_wg = rpw;

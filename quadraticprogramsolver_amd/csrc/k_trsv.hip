@@ -126,7 +126,9 @@ static int sweep_rb() { static int rb = [] { const char* e = getenv("QPS_SWEEP_R
 
 template <typename T> int sweep_fused_slabs(int NP, int count) {
     const int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
-    static const int total = [] { const char* e = getenv("QPS_SWEEP_WGS"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+    static const int total_env = [] { const char* e = getenv("QPS_SWEEP_WGS"); return e ? atoi(e) : 0; }();
+    const int kc = (NP + 512 * VecOf<T>::N - 1) / (512 * VecOf<T>::N);
+    const int total = total_env > 0 ? total_env : (kc <= 1 ? 1024 : (kc == 2 ? 512 : 256));   // by register footprint (72 / 100 / 156+ VGPRs)
     const int per = count >= total ? 1 : total / count;
     const int ntiles = NP / RB;
     return ntiles < per ? ntiles : per;

@@ -315,7 +315,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
     int* fail = nullptr; int* d_active = nullptr; double *d_rho = nullptr, *d_rhorho = nullptr;
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     int* h_int = nullptr; double* h_dbl = nullptr;   // pinned staging for the small per-QP arrays
-    bool have_AA = false; double fac_sigma = -1;
+    bool have_AA = false; double fac_sigma = -1; int fac_nb = -1; std::vector<double> fac_rho;   // per-QP factor cache
 
     BatchedDenseSolver(int dev, int cnt, int64_t n_, int64_t m_) {
         device = dev; n = n_; m = m_; count = cnt;
@@ -408,9 +408,13 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         for (int b = 0; b < count; ++b) all[b] = b;
         HIPC(hipMemsetAsync(fail, 0, sizeof(int) * count, st));
         const bool rebuild = !(p.reuseFactor && have_AA && fac_sigma == sigma);
-        for (int b = 0; b < count; ++b) factorize_one(b, p.rho, sigma, rebuild);                    // SolveQuadraticProgram.jl:36
-        check_fail(all);
-        have_AA = true; fac_sigma = sigma;
+        if ((int)fac_rho.size() != count) fac_rho.assign(count, -1.0);
+        std::vector<int> todo;
+        for (int b = 0; b < count; ++b)                                                             // SolveQuadraticProgram.jl:36
+            if (rebuild || fac_rho[b] != p.rho || fac_nb != nb) { factorize_one(b, p.rho, sigma, rebuild); todo.push_back(b); }
+        check_fail(todo);
+        have_AA = true; fac_sigma = sigma; fac_nb = nb;
+        for (int b : todo) fac_rho[b] = p.rho;
         for (int b = 0; b < count; ++b) put_vec(xh + (int64_t)b * n, x + (int64_t)b * NP, n);
         HIPC(hipMemsetAsync(z, 0, sizeof(T) * (size_t)count * MP, st));                             // :39
         HIPC(hipMemsetAsync(y, 0, sizeof(T) * (size_t)count * MP, st));                             // :40
@@ -433,6 +437,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 const double ta = now_s();
                 for (int b : changed) {
                     factorize_one(b, rho[b], sigma, false);
+                    fac_rho[b] = rho[b];
                     if (rhs_slabs > 0) {   // slabs of A'(rho z - y) depend on rho: rebuild them for this QP (slab 0 = the sum, rest 0)
                         T* pb_ = part + (int64_t)b * slabs * NP;
                         gemv_cols_partial<T>(st, A + (int64_t)b * MP * NP, NP, z + (int64_t)b * MP, y + (int64_t)b * MP, (T)rho[b], T(-1), part_tmp, NP, MP, NP);
