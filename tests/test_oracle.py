@@ -189,3 +189,26 @@ def test_qpmodel_mat_round_trip(tmp_path, c_oracle):
         x1, i1 = c_oracle.solve(P, q, A, l, u, numIterations=50, epsAbs=0.0, epsRel=0.0)
         x2, i2 = c_oracle.solve(P2, q2, A2, l2, u2, numIterations=50, epsAbs=0.0, epsRel=0.0)
         assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("pc,n,m,dense", [(ProblemClass.randomQp, 10, 0, False), (ProblemClass.inequalityConstrainedQp, 6, 0, False),
+                                          (ProblemClass.equalityConstrainedQp, 10, 5, True), (ProblemClass.optimalControl, 10, 0, False),
+                                          (ProblemClass.portfolioOptimization, 10, 0, False), (ProblemClass.lassoOptimization, 2, 0, False),
+                                          (ProblemClass.isotonicRegression, 10, 0, False)])
+def test_against_third_party_solver(c_oracle, pc, n, m, dense):
+    """RunTests.jl:62-99 with the role of OSQP/Gurobi played by a solver that IS available here: scipy's trust-constr
+    interior-point method, an implementation that shares nothing with the restatement.  Same assertion as the reference:
+    max|x_ref - x| <= absDevThr = 1e-5 (RunTests.jl:58,93)."""
+    from scipy.optimize import LinearConstraint, minimize
+    import warnings
+    P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 20), dense=dense, densityFctr=1.0 if dense else None)
+    Pd = P.toarray() if hasattr(P, "toarray") else P
+    Ad = A.toarray() if hasattr(A, "toarray") else A
+    x, info = c_oracle.solve(P, q, A, l, u, numIterations=50000, epsAbs=1e-9, epsRel=1e-9, rho=0.1, adptRho=True)
+    assert info["convFlag"] in (2, 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize(lambda v: 0.5 * v @ Pd @ v + q @ v, np.zeros(Pd.shape[0]), jac=lambda v: Pd @ v + q, hess=lambda v: Pd,
+                       method="trust-constr", constraints=[LinearConstraint(Ad, l, u)],
+                       options=dict(gtol=1e-10, xtol=1e-12, barrier_tol=1e-12, maxiter=5000))
+    assert np.abs(res.x - x).max() <= ABS_DEV_THR
