@@ -354,3 +354,40 @@ def test_large_n_falls_back_to_unfused_kernels(gpu):
         assert int(flag) == 3
         assert abs(info["resPrim"] - np.abs(A @ xk - zk).max()) <= 1e-9 and abs(info["resDual"] - np.abs(P @ xk + q + A.T @ yk).max()) <= 1e-8
         assert np.all(zk >= l - 1e-12) and np.all(zk <= u + 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's own test loop (RunTests.jl:62-99): every ProblemClass x sizes {10, 100} x several simulations with
+# numIterations = 50000, eps = 1e-7, rho = 0.1, adptRho = true and the assertion max|x_ref - x| <= 1e-5.  The
+# reference solver's role (OSQP/Gurobi) is played by the CPU oracle.  Classes 6-8 grow to (n + 100 n) variables, so their
+# second size is trimmed to what the dense CPU oracle can factor in a few seconds.
+# ------------------------------------------------------------------------------------------------------------------
+RUNTESTS_SIZES = {ProblemClass.randomQp: (10, 100), ProblemClass.inequalityConstrainedQp: (10, 100),
+                  ProblemClass.equalityConstrainedQp: (10, 100), ProblemClass.optimalControl: (10, 100),
+                  ProblemClass.portfolioOptimization: (10, 100), ProblemClass.lassoOptimization: (4, 10),
+                  ProblemClass.huberFitting: (2, 5), ProblemClass.supportVectorMachine: (4, 10),
+                  ProblemClass.isotonicRegression: (10, 100)}
+
+
+@pytest.mark.parametrize("pc", list(ProblemClass))
+def test_runtests_sweep(gpu, c_oracle, np_oracle, pc):
+    checked = 0
+    for sim in range(10):                                                       # RunTests.jl:29 numSimulations = 10
+        for n in RUNTESTS_SIZES[pc]:
+            m = (n // 2) if pc == ProblemClass.equalityConstrainedQp else 0     # RunTests.jl:39-47
+            P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(4321, 1000 * int(pc) + 10 * sim + (n > 10)))
+            xo, io = c_oracle.solve(P, q, A, l, u, numIterations=50000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
+            if io["convFlag"] == 1 or (io["convFlag"] == 2 and io["resPrim"] > 1e-4):
+                continue   # infeasible tiny draw (empty rows in A): ends by numIterations or by the stall test with rho at
+                           # its clamp, where the stopping iteration is roundoff-sensitive -- not a parity case
+            x = np.zeros(P.shape[0]); info = {}
+            with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+                flag = prob.solve(x, info=info, **REF_KW)                       # RunTests.jl:85
+                z, y = prob.dual()
+            assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"], (pc, n, sim, info, io["iterations"])
+            assert np.abs(x - xo).max() <= ABS_DEV_THR                          # RunTests.jl:93
+            if int(flag) == 3:
+                prim, dual, comp = np_oracle.kkt_certificate(x, y, P, q, A, l, u)
+                assert prim <= 1e-5 * max(1.0, np.abs(z).max()) and dual <= 1e-4 and comp <= 1e-4
+            checked += 1
+    assert checked >= 10
