@@ -58,6 +58,8 @@ def main():
     s = 8 if cfg["dtype"] == "f64" else 4
 
     device = info.local_rank if torch.cuda.device_count() > info.local_rank else 0
+    if torch.cuda.is_available():
+        torch.cuda.set_device(device)      # torch.cuda.synchronize() below must act on this rank's GPU, not on GPU 0
     if args.config in ("c3", "c4"):
         return side_config(args, cfg, info, backend, device, qps, qd, np, torch)
     # synthetic input: randomQp at density 1.0, seed 1234, one independent stream per rank (weak scaling)
