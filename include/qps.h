@@ -78,8 +78,10 @@ typedef struct {
     double epsMinres;        /* ϵMinres 1e-6 (ignored) */
     double epsPcg;           /* CG plugins' ϵPcg 1e-6 (LinearSystemSolvers.jl:125) */
     int32_t numItrPcg;       /* CG plugins' numItrPcg 1000 */
-    int32_t loopVariant;     /* additive: 0 = fused single pass over A per iteration when the shape allows (default),
-                                1 = unfused kernels (A read twice; the literal order of LinearSystemSolvers.jl:134-139) */
+    int32_t loopVariant;     /* additive: 0 = automatic: small problems run the whole loop in one single-workgroup launch,
+                                larger ones use the fused single pass over A per iteration when the shape allows (default);
+                                1 = unfused kernels (A read twice; the literal order of LinearSystemSolvers.jl:134-139);
+                                2 = multi-launch fused loop even for small problems */
 } qps_params;
 
 /* Additive out-of-band report (the reference returns only the flag, SolveQuadraticProgram.jl:73). */

@@ -257,7 +257,7 @@ template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg, int count
     // problems (KC == 1, <= 98 VGPRs) take four per CU (measured on 256 x n=1024: 164 k -> 213 k QP-iterations/s)
     static const int total_env = [] { const char* e = getenv("QPS_PASS_WGS"); return e ? atoi(e) : 0; }();
     const int kc1 = NP <= pass_threads() * VecOf<T>::N;
-    const int total = total_env > 0 ? total_env : (kc1 ? 1024 : 256);
+    const int total = total_env > 0 ? total_env : ((kc1 && count > 1) ? 1024 : 256);   // the wider launch pays for batches only
     const int target = count >= total ? 1 : total / (count < 1 ? 1 : count);
     int rpw = (MP + target - 1) / target;
     rpw = ((rpw + R - 1) / R) * R;

@@ -1,0 +1,228 @@
+// k_small.hip -- small-problem path: the WHOLE ADMM loop of SolveQuadraticProgram.jl:45-71 inside one kernel launch.
+//
+// For the reference's own test sizes (n = 10..100, RunTests.jl:30-38) an iteration moves a few hundred KB, so a loop built
+// from separate launches is bound by launch latency (~17 us/iteration measured = 4-5 kernel boundaries), slower than one CPU
+// thread.  Here ONE workgroup of 1024 threads keeps every vector in LDS, reads the (L2-resident) matrices with unit stride
+// and runs iterations back to back: linear solve, x/z/y update, and every numItrConv iterations CheckConvergence
+// (:79-112) with the rho proposal.  The kernel returns when a termination test fires, when the iteration budget is spent,
+// or when the proposed rho leaves the fctrRho band (:47) -- the host then re-factorises and relaunches.
+//
+// All four matrix-vector products are written as column accumulations  out[j] = sum_i Mat[i][j] v[i]  over row-major
+// storage (lanes along the contiguous index j): A'w uses A, z~ = A x~ uses a transposed copy At, the forward sweep uses
+// the upper triangle of S (= W'), the backward sweep the lower triangle (= W).  Requires one inverted block (nb >= n).
+#include <cstdlib>
+
+#include "qps_kernels.h"
+
+namespace qps {
+
+namespace {
+
+
+__device__ __forceinline__ unsigned long long absbits_s(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
+__device__ __forceinline__ double jmax_s(double a, double b) { return (isnan(a) || isnan(b)) ? (double)NAN : (a > b ? a : b); }
+
+// out[j] = pre(j) + sum_{i in rows, mask(i,j)} Mat[i*ld + j] * v[i],  j < ncols.  tri: 0 none, 1 keep i <= j, 2 keep i >= j.
+// Lanes run along j (J = power of two >= ncols, <= ST), the ST / J row groups split i; partial sums meet in LDS `scr`.
+template <typename T, int ST>
+__device__ __forceinline__ void gemv_cols_lds(const T* __restrict__ Mat, int ld, int nrows, int ncols, const T* v, T* out, T* scr, int tri) {
+    const int tid = threadIdx.x;
+    for (int j0 = 0; j0 < ncols; j0 += ST) {
+        const int nc = min(ncols - j0, ST);
+        int J = 64; while (J < nc) J <<= 1;
+        const int G = ST / J, jj = tid % J, g = tid / J, j = j0 + jj;
+        T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+        if (jj < nc) {
+            int ibeg = g, iend = nrows;
+            if (tri == 1) iend = min(nrows, j + 1);
+            if (tri == 2) { const int first = j; ibeg = first + ((g - first % G) % G + G) % G; }
+            const T* mp = Mat + j;
+            int i = ibeg;
+            for (; i + 3 * G < iend; i += 4 * G) {
+                a0 += mp[(int64_t)i * ld] * v[i];
+                a1 += mp[(int64_t)(i + G) * ld] * v[i + G];
+                a2 += mp[(int64_t)(i + 2 * G) * ld] * v[i + 2 * G];
+                a3 += mp[(int64_t)(i + 3 * G) * ld] * v[i + 3 * G];
+            }
+            for (; i < iend; i += G) a0 += mp[(int64_t)i * ld] * v[i];
+        }
+        scr[g * J + jj] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (g == 0 && jj < nc) {
+            T s = T(0);
+            for (int k = 0; k < G; ++k) s += scr[k * J + jj];   // fixed order
+            out[j] = s;
+        }
+        __syncthreads();
+    }
+}
+
+struct SmallArgs {
+    int n, m, NP, MP;
+    int it_begin, it_end, numItrConv, adptRho;     // iterations it_begin+1 .. it_end are run (1-based, as `ii` in the reference)
+    double rho, rhorho, sigma, alpha, epsAbs, epsRel, epsAdmm, fctrRho;
+};
+// status[0] last iteration executed, [1] convFlag, [2] need_rho (1: proposed rho left the band), doubles: res[0..7] as the check kernels
+struct SmallOut { int last_it, convFlag, need_rho, pad; double res[8]; };
+
+template <typename T, int ST>
+__global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restrict__ A, const T* __restrict__ At, const T* __restrict__ P,
+                                                   const T* __restrict__ S, const T* __restrict__ q, const T* __restrict__ l,
+                                                   const T* __restrict__ u, T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz,
+                                                   T* __restrict__ gy, SmallOut* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NP = a.NP, MP = a.MP, tid = threadIdx.x;
+    T* x = reinterpret_cast<T*>(smem);          // NP
+    T* xp = x + NP; T* xx = xp + NP; T* t = xx + NP; T* yv = t + NP; T* qv = yv + NP;     // 6 NP
+    T* z = qv + NP; T* zp = z + MP; T* y = zp + MP; T* zz = y + MP; T* w = zz + MP; T* lv = w + MP; T* uv = lv + MP;   // 7 MP
+    T* scr = uv + MP;                           // ST
+    __shared__ unsigned long long nrm[9];
+    __shared__ int sh_flag, sh_need;
+    __shared__ double sh_rhorho;
+
+    for (int i = tid; i < NP; i += ST) { x[i] = gx[i]; xp[i] = gxp[i]; qv[i] = q[i]; xx[i] = T(0); }
+    for (int i = tid; i < MP; i += ST) { z[i] = gz[i]; y[i] = gy[i]; lv[i] = l[i]; uv[i] = u[i]; zp[i] = T(0); }
+    if (tid == 0) { sh_flag = 1; sh_need = 0; sh_rhorho = a.rhorho; }
+    __syncthreads();
+    const T rho = (T)a.rho, rho1 = T(1) / rho, sigma = (T)a.sigma, alpha = (T)a.alpha, alpha1 = T(1) - alpha;
+    int it = a.it_begin;
+    double res[8] = {NAN, NAN, NAN, NAN, a.rhorho, 1.0, NAN, NAN};
+    while (it < a.it_end) {
+        ++it;
+        // LinearSystemSolvers.jl:134-139 (reduced form, Cholesky instead of cg!)
+        for (int i = tid; i < MP; i += ST) w[i] = rho * z[i] - y[i];                        // :134
+        __syncthreads();
+        gemv_cols_lds<T, ST>(A, NP, a.m, NP, w, t, scr, 0);                                       // :135  A' w
+        for (int i = tid; i < NP; i += ST) t[i] = sigma * x[i] - qv[i] + t[i];                // :136
+        __syncthreads();
+        gemv_cols_lds<T, ST>(S, NP, NP, NP, t, yv, scr, 1);                                       // forward sweep:  y = W t   (rows of W' = upper part)
+        gemv_cols_lds<T, ST>(S, NP, NP, NP, yv, xx, scr, 2);                                      // backward sweep: x~ = W' y (rows of W = lower part)
+        gemv_cols_lds<T, ST>(At, MP, a.n, MP, xx, zz, scr, 0);                                    // :139  z~ = A x~
+        // SolveQuadraticProgram.jl:56-61
+        for (int i = tid; i < NP; i += ST) { const T xo = x[i]; xp[i] = xo; x[i] = alpha * xx[i] + alpha1 * xo; }
+        for (int i = tid; i < MP; i += ST) {
+            const T zo = z[i], yo = y[i], zt = zz[i];
+            zp[i] = zo;
+            const T tt = alpha * zt + alpha1 * zo + rho1 * yo;
+            const T zn = tt > uv[i] ? uv[i] : (tt < lv[i] ? lv[i] : tt);
+            z[i] = zn;
+            y[i] = yo + rho * (alpha * zt + alpha1 * zo - zn);
+        }
+        __syncthreads();
+        if (it % a.numItrConv == 0) {                                                         // :63  CheckConvergence :79-112
+            T* Ax = zz; T* Px = t; T* Aty = yv;                                               // scratch vectors are free here
+            gemv_cols_lds<T, ST>(At, MP, a.n, MP, x, Ax, scr, 0);
+            gemv_cols_lds<T, ST>(P, NP, a.n, NP, x, Px, scr, 0);
+            gemv_cols_lds<T, ST>(A, NP, a.m, NP, y, Aty, scr, 0);
+            if (tid < 9) nrm[tid] = 0ull;
+            __syncthreads();
+            unsigned long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = tid; i < max(a.n, a.m); i += ST) {
+                if (i < a.m) {
+                    v[0] = max(v[0], absbits_s((double)(Ax[i] - z[i]))); v[2] = max(v[2], absbits_s((double)Ax[i]));
+                    v[3] = max(v[3], absbits_s((double)z[i])); v[8] = max(v[8], absbits_s((double)(z[i] - zp[i])));
+                }
+                if (i < a.n) {
+                    v[1] = max(v[1], absbits_s((double)(Px[i] + qv[i] + Aty[i]))); v[4] = max(v[4], absbits_s((double)Px[i]));
+                    v[5] = max(v[5], absbits_s((double)Aty[i])); v[6] = max(v[6], absbits_s((double)qv[i]));
+                    v[7] = max(v[7], absbits_s((double)(x[i] - xp[i])));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long tv = __shfl_xor(v[k], o, 64); v[k] = tv > v[k] ? tv : v[k]; }
+                if ((tid & 63) == 0 && v[k]) atomicMax(&nrm[k], v[k]);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double nv[9];
+                for (int k = 0; k < 9; ++k) nv[k] = __longlong_as_double((long long)nrm[k]);
+                const double normResPrim = nv[0], normResDual = nv[1];                        // :85-86
+                const double maxNormPrim = jmax_s(nv[2], nv[3]);                              // :88
+                const double maxNormDual = jmax_s(jmax_s(nv[4], nv[5]), nv[6]);               // :89
+                double rr = sh_rhorho;
+                if (a.adptRho) {                                                              // :92-96
+                    const double tv = a.rho * sqrt((normResPrim * maxNormDual) / (normResDual * maxNormPrim));
+                    rr = tv > 1e6 ? 1e6 : (tv < 1e-3 ? 1e-3 : tv);
+                }
+                int flag = 1;
+                if ((normResPrim < a.epsAbs + a.epsRel * maxNormPrim) && (normResDual < a.epsAbs + a.epsRel * maxNormDual)) flag = 3;   // :102-104
+                if ((nv[7] <= a.epsAdmm) && (nv[8] <= a.epsAdmm)) flag = 2;                   // :105-107 (not else)
+                sh_rhorho = rr; sh_flag = flag;
+                sh_need = (flag == 1 && a.adptRho && ((rr * a.fctrRho < a.rho) || (rr > a.fctrRho * a.rho))) ? 1 : 0;   // :47
+                res[0] = normResPrim; res[1] = normResDual; res[2] = maxNormPrim; res[3] = maxNormDual; res[4] = rr; res[5] = flag;
+                res[6] = nv[7]; res[7] = nv[8];
+            }
+            __syncthreads();
+            if (sh_flag != 1 || sh_need) break;
+        }
+    }
+    for (int i = tid; i < NP; i += ST) { gx[i] = x[i]; gxp[i] = xp[i]; }
+    for (int i = tid; i < MP; i += ST) { gz[i] = z[i]; gy[i] = y[i]; }
+    if (tid == 0) {
+        out->last_it = it; out->convFlag = sh_flag; out->need_rho = sh_need;
+        for (int k = 0; k < 8; ++k) out->res[k] = res[k];
+        out->res[4] = sh_rhorho;
+    }
+}
+
+// At[c][r] = A[r][c]  (A row-major MP x NP, At row-major NP x MP); sizes are small here
+template <typename T> __global__ void k_transpose_small(const T* __restrict__ A, int NP, int MP, T* __restrict__ At) {
+    const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (r < MP) At[(int64_t)c * MP + r] = A[(int64_t)r * NP + c];
+}
+
+template <typename T> size_t small_lds_bytes(int NP, int MP) { return sizeof(T) * ((size_t)6 * NP + (size_t)7 * MP + 1024); }
+
+}  // namespace
+
+template <typename T> bool admm_small_supported(int n, int m, int NP, int MP) {
+    if (m < 1 || NP > 512 || MP > 2048) return false;
+    if (small_lds_bytes<T>(NP, MP) > 150 * 1024) return false;
+    const double bytes = ((double)2 * MP * NP + (double)NP * NP) * sizeof(T);
+    return bytes <= 1.25 * 1024 * 1024;       // beyond ~1 MiB per iteration one CU's L2 bandwidth loses to the multi-CU loop
+}
+
+template <typename T>
+void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int it_end, int numItrConv, int adptRho, double rho,
+                double rhorho, double sigma, double alpha, double epsAbs, double epsRel, double epsAdmm, double fctrRho, const T* A,
+                const T* At, const T* P, const T* S, const T* q, const T* l, const T* u, T* x, T* xp, T* z, T* y, void* out_dev) {
+    SmallArgs a{n, m, NP, MP, it_begin, it_end, numItrConv, adptRho, rho, rhorho, sigma, alpha, epsAbs, epsRel, epsAdmm, fctrRho};
+    const size_t lds = small_lds_bytes<T>(NP, MP);
+    static const int th_env = [] { const char* e = getenv("QPS_SMALL_THREADS"); return e ? atoi(e) : 0; }();
+    // few waves for tiny problems (a workgroup barrier costs with the number of waves), 1024 threads once there is work for them
+    const int th = th_env > 0 ? th_env : ((int64_t)MP * NP <= 65536 ? 512 : 1024);   // measured at n = 10 / 64 / 100: 512 beats 256 and 1024
+    static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+    const int ti = sizeof(T) == 8 ? 0 : 1;
+#define QPS_SMALL(THN, IDX)                                                                                                                  \
+    do {                                                                                                                                     \
+        if (!attr_set[ti][IDX]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[ti][IDX] = true; } \
+        hipLaunchKernelGGL((k_admm_small<T, THN>), dim3(1), dim3(THN), lds, st, a, A, At, P, S, q, l, u, x, xp, z, y, reinterpret_cast<SmallOut*>(out_dev)); \
+    } while (0)
+    if (th <= 256) QPS_SMALL(256, 0); else if (th <= 512) QPS_SMALL(512, 1); else QPS_SMALL(1024, 2);
+#undef QPS_SMALL
+}
+
+template <typename T> void transpose_small(hipStream_t st, const T* A, int NP, int MP, T* At) {
+    if (NP <= 0 || MP <= 0) return;
+    hipLaunchKernelGGL((k_transpose_small<T>), dim3((MP + 255) / 256, NP), dim3(256), 0, st, A, NP, MP, At);
+}
+
+size_t admm_small_out_bytes() { return sizeof(SmallOut); }
+void admm_small_read(const void* host_copy, int* last_it, int* convFlag, int* need_rho, double* res8) {
+    const SmallOut* o = reinterpret_cast<const SmallOut*>(host_copy);
+    *last_it = o->last_it; *convFlag = o->convFlag; *need_rho = o->need_rho;
+    for (int k = 0; k < 8; ++k) res8[k] = o->res[k];
+}
+
+#define INST(T)                                                                                                                    \
+    template void transpose_small<T>(hipStream_t, const T*, int, int, T*);                                                         \
+    template bool admm_small_supported<T>(int, int, int, int);                                                                     \
+    template void admm_small<T>(hipStream_t, int, int, int, int, int, int, int, int, double, double, double, double, double, double, \
+                                double, double, const T*, const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*, void*);
+INST(double)
+INST(float)
+#undef INST
+
+}  // namespace qps

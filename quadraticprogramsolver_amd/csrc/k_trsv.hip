@@ -128,7 +128,7 @@ template <typename T> int sweep_fused_slabs(int NP, int count) {
     const int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
     static const int total_env = [] { const char* e = getenv("QPS_SWEEP_WGS"); return e ? atoi(e) : 0; }();
     const int kc = (NP + 512 * VecOf<T>::N - 1) / (512 * VecOf<T>::N);
-    const int total = total_env > 0 ? total_env : (kc <= 1 ? 1024 : (kc == 2 ? 512 : 256));   // by register footprint (72 / 100 / 156+ VGPRs)
+    const int total = total_env > 0 ? total_env : (count <= 1 ? 256 : (kc <= 1 ? 1024 : (kc == 2 ? 512 : 256)));   // batches: by register footprint
     const int per = count >= total ? 1 : total / count;
     const int ntiles = NP / RB;
     return ntiles < per ? ntiles : per;

@@ -29,6 +29,7 @@ template <typename T> struct DenseSolver : SolverBase {
     T *PI = nullptr, *AA = nullptr, *M = nullptr, *S = nullptr, *tmp = nullptr, *dinv = nullptr; int* fail = nullptr;
     T *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr, *xx = nullptr, *zz = nullptr, *tt = nullptr, *yv = nullptr;
     T *part = nullptr, *part2 = nullptr, *sw_part = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
+    T* At = nullptr; void* small_out = nullptr; void* small_out_host = nullptr; bool small_ok = false;   // small-problem path
     int pass_slabs = 0, pass_rpw = 0;   // fused-pass plan (0 slabs: shape not supported, unfused loop only)
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
@@ -57,6 +58,12 @@ template <typename T> struct DenseSolver : SolverBase {
         scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
         HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
         stage = dalloc<double>((int64_t)NP + 2 * (int64_t)MP + 64);
+        small_ok = admm_small_supported<T>((int)n, (int)m, NP, MP);
+        if (small_ok) {
+            At = dalloc<T>((int64_t)NP * MP);
+            small_out = dalloc<double>(32);
+            HIPC(hipHostMalloc(&small_out_host, 256));
+        }
         const double s = sizeof(T);
         // algorithmic bytes per launch (SURVEY §8d "per-kernel algorithmic bytes")
         cat_atw = prof.category("gemv_cols(A'w)", s * ((double)m * n + m + n));
@@ -77,9 +84,10 @@ template <typename T> struct DenseSolver : SolverBase {
     ~DenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
-        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, sw_part, Ax, Px, Aty, scratch, res_dev, stage};
+        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, sw_part, Ax, Px, Aty, scratch, res_dev, stage, At, small_out};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (res_host) (void)hipHostFree(res_host);
+        if (small_out_host) (void)hipHostFree(small_out_host);
         if (st) (void)hipStreamDestroy(st);
     }
 
@@ -198,6 +206,37 @@ template <typename T> struct DenseSolver : SolverBase {
         const double t1 = now_s();
         double rhorho = rho;                                                                        // :43
         int ii = 0, nref = 0; double tref = 0, resP = NAN, resD = NAN;
+        if (small_ok && p.loopVariant == 0 && (NP + nb - 1) / nb == 1) {
+            // Small problem: the whole loop :45-71 runs inside one single-workgroup launch; the host only steps in for a rho switch.
+            transpose_small<T>(st, A, NP, MP, At);
+            int it = 0;
+            while (it < p.numIterations) {
+                admm_small<T>(st, (int)n, (int)m, NP, MP, it, p.numIterations, p.numItrConv, p.adptRho, rho, rhorho, sigma, alpha, p.epsAbs,
+                              p.epsRel, epsAdmm, p.fctrRho, A, At, P, S, q, l, u, x, xp, z, y, small_out);
+                HIPC(hipMemcpyAsync(small_out_host, small_out, admm_small_out_bytes(), hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                int last = 0, flag = 1, need = 0; double r8[8];
+                admm_small_read(small_out_host, &last, &flag, &need, r8);
+                it = last; convFlag = flag; rhorho = r8[4];
+                if (!std::isnan(r8[0]) || !std::isnan(r8[1])) { resP = r8[0]; resD = r8[1]; }
+                if (flag != QPS_CONV_NUM_ITR) break;                                                // :66-68
+                if (need) {                                                                         // :47-51
+                    rho = rhorho; ++nref;
+                    const double ta = now_s();
+                    factorize(rho, sigma, false);
+                    tref += now_s() - ta;
+                }
+            }
+            ii = it;
+            const double t2s = now_s();
+            download_vec(x, xh, n);
+            if (info) {
+                info->convFlag = convFlag; info->iterations = ii; info->numRefactor = nref; info->cgIterations = 0;
+                info->rhoFinal = rho; info->rhoProposed = rhorho; info->resPrim = resP; info->resDual = resD;
+                info->tSetup = t1 - t0; info->tLoop = t2s - t1; info->tRefactor = tref;
+            }
+            return;
+        }
         const bool fused = pass_slabs > 0 && p.loopVariant != 1;
         int rhs_slabs = 0;   // z = y = 0: A'(rho z - y) = 0, no slab to add for the first right-hand side
         for (ii = 1; ii <= p.numIterations; ++ii) {                                                 // :45

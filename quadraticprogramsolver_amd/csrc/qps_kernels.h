@@ -76,6 +76,18 @@ template <typename T> int sweep_fused_slabs(int NP, int count = 1);
 template <typename T>
 int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* part, int64_t part_ld, BatchStride bs = BatchStride());
 
+// ---- small-problem path (k_small.hip): the whole loop in one single-workgroup launch ---------------------------------------
+template <typename T> bool admm_small_supported(int n, int m, int NP, int MP);
+template <typename T> void transpose_small(hipStream_t st, const T* A, int NP, int MP, T* At);
+// runs iterations it_begin+1 .. it_end (or until a termination test fires / the proposed rho leaves the fctrRho band);
+// out_dev receives {last iteration, convFlag, need_rho, res[8]} (admm_small_out_bytes / admm_small_read)
+template <typename T>
+void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int it_end, int numItrConv, int adptRho, double rho,
+                double rhorho, double sigma, double alpha, double epsAbs, double epsRel, double epsAdmm, double fctrRho, const T* A,
+                const T* At, const T* P, const T* S, const T* q, const T* l, const T* u, T* x, T* xp, T* z, T* y, void* out_dev);
+size_t admm_small_out_bytes();
+void admm_small_read(const void* host_copy, int* last_it, int* convFlag, int* need_rho, double* res8);
+
 template <typename T> void fill(hipStream_t st, T* p, int64_t n, T v);
 template <typename T> void convert_copy(hipStream_t st, const double* src, T* dst, int64_t n);   // dst[i] = (T)src[i]
 template <typename T> void convert_back(hipStream_t st, const T* src, double* dst, int64_t n);   // dst[i] = (double)src[i]

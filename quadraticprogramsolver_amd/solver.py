@@ -256,7 +256,7 @@ HipCholF32Init, HipCholF32 = _make_pair("cholesky", "f32")
 def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholInit, LinSysSol=HipChol, *,
                                  numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=False,
                                  fctrΡ=5, numItrConv=25, numItrPolish=10, ϵMinres=1e-6, numItrMinres=500, info=None,
-                                 device=0, trsvBlock=0):
+                                 device=0, trsvBlock=0, loopVariant=0):
     """``SolveQuadraticProgram!`` (SolveQuadraticProgram.jl:14-76): mutates ``vX``, returns the ConvergenceFlag.
 
     ``δ, numItrPolish, ϵMinres, numItrMinres`` are accepted and ignored, as in the reference (:16-17, no polish).
@@ -268,7 +268,7 @@ def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholIn
     with QuadraticProgram(mP, vQ, mA, vL, vU, linsys=linsys, dtype=LinSysSolInit._qps_dtype, device=device) as prob:
         return prob.solve(vX, numIterations=numIterations, ϵAbs=ϵAbs, ϵRel=ϵRel, ρ=ρ, σ=σ, α=α, δ=δ, adptΡ=adptΡ,
                           fctrΡ=fctrΡ, numItrConv=numItrConv, numItrPolish=numItrPolish, ϵMinres=ϵMinres,
-                          numItrMinres=numItrMinres, trsvBlock=trsvBlock, info=info)
+                          numItrMinres=numItrMinres, trsvBlock=trsvBlock, loopVariant=loopVariant, info=info)
 
 
 SolveQuadraticProgram_b = SolveQuadraticProgramInplace

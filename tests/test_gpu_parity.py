@@ -22,26 +22,29 @@ def rel(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if b.size else 0.0
 
 
+@pytest.mark.parametrize("variant", [0, 2])   # 0: automatic (these sizes: whole loop in one launch); 2: multi-launch fused loop
 @pytest.mark.parametrize("name", GOLDEN_PROBLEMS)
-def test_golden_iterates(gpu, name):
+def test_golden_iterates(gpu, name, variant):
     g = load_golden(name)
     with gpu.QuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"]) as prob:
         for K in (25, 50, 100):
             x = np.zeros(g["P"].shape[0]); info = {}
-            flag = prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+            flag = prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, loopVariant=variant, info=info)
             z, y = prob.dual()
             assert flag == gpu.ConvergenceFlag.convNumItr and info["iterations"] == K
             assert rel(x, g[f"x_K{K}"]) <= 1e-9 and rel(z, g[f"z_K{K}"]) <= 1e-9 and rel(y, g[f"y_K{K}"]) <= 1e-8
 
 
+@pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("name", GOLDEN_PROBLEMS)
-def test_golden_solutions(gpu, name):
+def test_golden_solutions(gpu, name, variant):
     g = load_golden(name)
     kw = dict(REF_KW)
     if name == "c1_randomQp_n64_m128":
         kw["numIterations"] = 200
     x = np.zeros(g["P"].shape[0]); info = {}
-    flag = gpu.SolveQuadraticProgramInplace(x, g["P"], g["q"], g["A"], g["l"], g["u"], gpu.HipCholInit, gpu.HipChol, info=info, **kw)
+    flag = gpu.SolveQuadraticProgramInplace(x, g["P"], g["q"], g["A"], g["l"], g["u"], gpu.HipCholInit, gpu.HipChol, info=info,
+                                            loopVariant=variant, **kw)
     assert int(flag) == int(g["flag"]) and info["iterations"] == int(g["iterations"]) and info["numRefactor"] == int(g["n_refactor"])
     assert np.abs(x - g["x_final"]).max() <= ABS_DEV_THR
 
@@ -69,7 +72,7 @@ def test_iterates_match_oracle_all_classes(gpu, c_oracle, pc, n, m, dense):
     P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 40 + int(pc)), dense=dense,
                                      densityFctr=1.0 if dense else None)
     with gpu.QuadraticProgram(P, q, A, l, u) as prob:
-        for K, nb, variant in ((25, 0, 0), (100, 64, 0), (50, 256, 1), (75, 0, 0)):   # variant 1 = unfused kernels
+        for K, nb, variant in ((25, 0, 0), (100, 64, 0), (50, 256, 1), (75, 0, 2), (60, 0, 0)):   # 1 = unfused kernels, 2 = multi-launch
             x = np.zeros(P.shape[0]); info = {}
             prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, trsvBlock=nb, loopVariant=variant, info=info)
             z, y = prob.dual()
@@ -97,18 +100,19 @@ def test_solutions_match_oracle_and_kkt(gpu, c_oracle, np_oracle, pc, n, m, dens
 
 @pytest.mark.parametrize("name", ["c1_randomQp_feasible_n64_m128", "c1_isotonicRegression_n64"])
 def test_fused_and_unfused_loops_agree(gpu, name):
-    """The fused single-pass loop and the literal LinearSystemSolvers.jl:134-139 kernel order give the same run,
+    """The single-launch small-problem loop, the fused multi-launch loop and the literal LinearSystemSolvers.jl:134-139 kernel order give the same run,
     including the rho switches (the slabs of A'(rho z - y) are rebuilt on changedΡ)."""
     g = load_golden(name)
     out = []
     with gpu.QuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"]) as prob:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             x = np.zeros(g["P"].shape[0]); info = {}
             flag = prob.solve(x, loopVariant=variant, info=info, **REF_KW)
             out.append((x, int(flag), info["iterations"], info["numRefactor"], info["resPrim"], info["resDual"]))
-    assert out[0][1:4] == out[1][1:4] == (int(g["flag"]), int(g["iterations"]), int(g["n_refactor"]))
-    assert rel(out[0][0], out[1][0]) <= 1e-9
-    assert abs(out[0][4] - out[1][4]) <= 1e-9 * max(1.0, out[1][4]) and abs(out[0][5] - out[1][5]) <= 1e-9 * max(1.0, out[1][5])
+    assert out[0][1:4] == out[1][1:4] == out[2][1:4] == (int(g["flag"]), int(g["iterations"]), int(g["n_refactor"]))
+    for o in out[1:]:
+        assert rel(out[0][0], o[0]) <= 1e-9
+        assert abs(out[0][4] - o[4]) <= 1e-9 * max(1.0, o[4]) and abs(out[0][5] - o[5]) <= 1e-9 * max(1.0, o[5])
 
 
 def test_plugin_pair_drives_reference_loop(gpu, np_oracle):
