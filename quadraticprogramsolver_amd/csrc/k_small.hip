@@ -57,6 +57,25 @@ __device__ __forceinline__ void gemv_cols_lds(const T* __restrict__ Mat, int ld,
     }
 }
 
+// out[r] = sum_c Al[r * lda + c] * v[c] for an LDS-resident matrix with an ODD row stride in 8-byte words (lda = NP + 1):
+// PARTS threads share a row (contiguous column ranges), lanes of a wave sit on different rows => conflict-free reads.
+template <typename T, int ST>
+__device__ __forceinline__ void gemv_rows_ldsmat(const T* Al, int lda, int nrows, int ncols, const T* v, T* out, T* scr) {
+    const int tid = threadIdx.x;
+    int R = 64; while (R < nrows && R < ST) R <<= 1;          // lanes along rows
+    const int PARTS = ST / R, r = tid % R, part = tid / R;
+    const int span = (ncols + PARTS - 1) / PARTS, c0 = part * span, c1 = min(ncols, c0 + span);
+    for (int rb = 0; rb < nrows; rb += R) {
+        T s = T(0);
+        const int row = rb + r;
+        if (row < nrows) { const T* ap = Al + (size_t)row * lda; for (int c = c0; c < c1; ++c) s += ap[c] * v[c]; }
+        scr[part * R + r] = s;
+        __syncthreads();
+        if (part == 0 && row < nrows) { T tsum = T(0); for (int p = 0; p < PARTS; ++p) tsum += scr[p * R + r]; out[row] = tsum; }
+        __syncthreads();
+    }
+}
+
 struct SmallArgs {
     int n, m, NP, MP;
     int it_begin, it_end, numItrConv, adptRho;     // iterations it_begin+1 .. it_end are run (1-based, as `ii` in the reference)
@@ -65,7 +84,7 @@ struct SmallArgs {
 // status[0] last iteration executed, [1] convFlag, [2] need_rho (1: proposed rho left the band), doubles: res[0..7] as the check kernels
 struct SmallOut { int last_it, convFlag, need_rho, pad; double res[8]; };
 
-template <typename T, int ST>
+template <typename T, int ST, bool LM>
 __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restrict__ A, const T* __restrict__ At, const T* __restrict__ P,
                                                    const T* __restrict__ S, const T* __restrict__ q, const T* __restrict__ l,
                                                    const T* __restrict__ u, T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz,
@@ -75,7 +94,16 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
     T* x = reinterpret_cast<T*>(smem);          // NP
     T* xp = x + NP; T* xx = xp + NP; T* t = xx + NP; T* yv = t + NP; T* qv = yv + NP;     // 6 NP
     T* z = qv + NP; T* zp = z + MP; T* y = zp + MP; T* zz = y + MP; T* w = zz + MP; T* lv = w + MP; T* uv = lv + MP;   // 7 MP
-    T* scr = uv + MP;                           // ST
+    T* scr = uv + MP;                           // 1024
+    // LM: A (row stride NP + 1, conflict-free row walks) and S are copied into LDS once per launch
+    T* Al = scr + 1024; const int lda = NP + 1;
+    T* Sl = Al + (LM ? (size_t)MP * lda : 0);
+    if (LM) {
+        for (int i = tid; i < MP * NP; i += ST) { const int r = i / NP, c = i - r * NP; Al[(size_t)r * lda + c] = A[i]; }
+        for (int i = tid; i < NP * NP; i += ST) Sl[i] = S[i];
+    }
+    const T* Am = LM ? Al : A; const int ldA = LM ? lda : NP;
+    const T* Sm = LM ? Sl : S;
     __shared__ unsigned long long nrm[9];
     __shared__ int sh_flag, sh_need;
     __shared__ double sh_rhorho;
@@ -92,12 +120,13 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
         // LinearSystemSolvers.jl:134-139 (reduced form, Cholesky instead of cg!)
         for (int i = tid; i < MP; i += ST) w[i] = rho * z[i] - y[i];                        // :134
         __syncthreads();
-        gemv_cols_lds<T, ST>(A, NP, a.m, NP, w, t, scr, 0);                                       // :135  A' w
+        gemv_cols_lds<T, ST>(Am, ldA, a.m, NP, w, t, scr, 0);                                     // :135  A' w
         for (int i = tid; i < NP; i += ST) t[i] = sigma * x[i] - qv[i] + t[i];                // :136
         __syncthreads();
-        gemv_cols_lds<T, ST>(S, NP, NP, NP, t, yv, scr, 1);                                       // forward sweep:  y = W t   (rows of W' = upper part)
-        gemv_cols_lds<T, ST>(S, NP, NP, NP, yv, xx, scr, 2);                                      // backward sweep: x~ = W' y (rows of W = lower part)
-        gemv_cols_lds<T, ST>(At, MP, a.n, MP, xx, zz, scr, 0);                                    // :139  z~ = A x~
+        gemv_cols_lds<T, ST>(Sm, NP, NP, NP, t, yv, scr, 1);                                      // forward sweep:  y = W t   (rows of W' = upper part)
+        gemv_cols_lds<T, ST>(Sm, NP, NP, NP, yv, xx, scr, 2);                                     // backward sweep: x~ = W' y (rows of W = lower part)
+        if (LM) gemv_rows_ldsmat<T, ST>(Al, lda, MP, NP, xx, zz, scr);                            // :139  z~ = A x~
+        else gemv_cols_lds<T, ST>(At, MP, a.n, MP, xx, zz, scr, 0);
         // SolveQuadraticProgram.jl:56-61
         for (int i = tid; i < NP; i += ST) { const T xo = x[i]; xp[i] = xo; x[i] = alpha * xx[i] + alpha1 * xo; }
         for (int i = tid; i < MP; i += ST) {
@@ -111,9 +140,10 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
         __syncthreads();
         if (it % a.numItrConv == 0) {                                                         // :63  CheckConvergence :79-112
             T* Ax = zz; T* Px = t; T* Aty = yv;                                               // scratch vectors are free here
-            gemv_cols_lds<T, ST>(At, MP, a.n, MP, x, Ax, scr, 0);
+            if (LM) gemv_rows_ldsmat<T, ST>(Al, lda, MP, NP, x, Ax, scr);
+            else gemv_cols_lds<T, ST>(At, MP, a.n, MP, x, Ax, scr, 0);
             gemv_cols_lds<T, ST>(P, NP, a.n, NP, x, Px, scr, 0);
-            gemv_cols_lds<T, ST>(A, NP, a.m, NP, y, Aty, scr, 0);
+            gemv_cols_lds<T, ST>(Am, ldA, a.m, NP, y, Aty, scr, 0);
             if (tid < 9) nrm[tid] = 0ull;
             __syncthreads();
             unsigned long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -174,6 +204,7 @@ template <typename T> __global__ void k_transpose_small(const T* __restrict__ A,
 }
 
 template <typename T> size_t small_lds_bytes(int NP, int MP) { return sizeof(T) * ((size_t)6 * NP + (size_t)7 * MP + 1024); }
+template <typename T> size_t small_lds_mat_bytes(int NP, int MP) { return sizeof(T) * ((size_t)MP * (NP + 1) + (size_t)NP * NP); }
 
 }  // namespace
 
@@ -189,18 +220,23 @@ void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int 
                 double rhorho, double sigma, double alpha, double epsAbs, double epsRel, double epsAdmm, double fctrRho, const T* A,
                 const T* At, const T* P, const T* S, const T* q, const T* l, const T* u, T* x, T* xp, T* z, T* y, void* out_dev) {
     SmallArgs a{n, m, NP, MP, it_begin, it_end, numItrConv, adptRho, rho, rhorho, sigma, alpha, epsAbs, epsRel, epsAdmm, fctrRho};
-    const size_t lds = small_lds_bytes<T>(NP, MP);
+    size_t lds = small_lds_bytes<T>(NP, MP);
+    static const int lm_env = [] { const char* e = getenv("QPS_SMALL_LDSMAT"); return e ? atoi(e) : 1; }();
+    const bool lm = lm_env && (lds + small_lds_mat_bytes<T>(NP, MP) <= 158 * 1024);
+    if (lm) lds += small_lds_mat_bytes<T>(NP, MP);
     static const int th_env = [] { const char* e = getenv("QPS_SMALL_THREADS"); return e ? atoi(e) : 0; }();
     // few waves for tiny problems (a workgroup barrier costs with the number of waves), 1024 threads once there is work for them
     const int th = th_env > 0 ? th_env : ((int64_t)MP * NP <= 65536 ? 512 : 1024);   // measured at n = 10 / 64 / 100: 512 beats 256 and 1024
-    static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+    static bool attr_set[2][3][2] = {};
     const int ti = sizeof(T) == 8 ? 0 : 1;
-#define QPS_SMALL(THN, IDX)                                                                                                                  \
+#define QPS_SMALL(THN, IDX, LMV)                                                                                                             \
     do {                                                                                                                                     \
-        if (!attr_set[ti][IDX]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[ti][IDX] = true; } \
-        hipLaunchKernelGGL((k_admm_small<T, THN>), dim3(1), dim3(THN), lds, st, a, A, At, P, S, q, l, u, x, xp, z, y, reinterpret_cast<SmallOut*>(out_dev)); \
+        if (!attr_set[ti][IDX][LMV]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN, (LMV) != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[ti][IDX][LMV] = true; } \
+        hipLaunchKernelGGL((k_admm_small<T, THN, (LMV) != 0>), dim3(1), dim3(THN), lds, st, a, A, At, P, S, q, l, u, x, xp, z, y, reinterpret_cast<SmallOut*>(out_dev)); \
     } while (0)
-    if (th <= 256) QPS_SMALL(256, 0); else if (th <= 512) QPS_SMALL(512, 1); else QPS_SMALL(1024, 2);
+#define QPS_SMALL2(THN, IDX) do { if (lm) QPS_SMALL(THN, IDX, 1); else QPS_SMALL(THN, IDX, 0); } while (0)
+    if (th <= 256) QPS_SMALL2(256, 0); else if (th <= 512) QPS_SMALL2(512, 1); else QPS_SMALL2(1024, 2);
+#undef QPS_SMALL2
 #undef QPS_SMALL
 }
 
