@@ -84,8 +84,11 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise QpsLibraryError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                              "(there is no CPU fallback)")
+        try:
+            build()          # compile in-tree for gfx950 (hipcc cross-compiles without a GPU); never a CPU substitute
+        except Exception as e:
+            raise QpsLibraryError(f"{LIB_PATH} not found and building it failed ({e}): run "
+                                  "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)") from e
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -1,6 +1,6 @@
 """Ad-hoc C2 timing: one configuration, all-kernel profile (not a test)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 n, m = 4096, 8192

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 P, qq, A, l, u = q.GenerateSparseBenchmarkQP(50000, 100000)

@@ -1,6 +1,6 @@
 """Ad-hoc timing of BASELINE config 3 (sparse n=50k, m=100k, ~0.1 % nnz, CSR/CG path).  Not a test."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 n, m = int(os.environ.get("QPS_N", 50000)), int(os.environ.get("QPS_M", 100000))

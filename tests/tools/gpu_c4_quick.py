@@ -1,6 +1,6 @@
 """Ad-hoc timing of BASELINE config 4 on one GPU: 32 dense QPs (n=1024, m=2048, fp64) = one rank's slab of 256/8."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 cnt, n, m = int(os.environ.get("QPS_CNT", 32)), 1024, 2048

@@ -1,6 +1,6 @@
 """Ad-hoc GPU bring-up script (not a test): compares libqps_hip with the CPU oracle on a few sizes and prints timings."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 from oracle import c_oracle as co

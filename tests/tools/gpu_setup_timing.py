@@ -1,6 +1,6 @@
 """Ad-hoc: setup / refactor timing at C2 size for fp64 and fp32 (config 5 style run).  Not a test."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 P, qq, A, l, u = q.GenerateDenseBenchmarkQP(4096, 8192)

@@ -1,6 +1,6 @@
 """Ad-hoc: iterations/s at the reference's own test sizes, GPU loop vs the CPU port (1 thread)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quadraticprogramsolver_amd as q
 from oracle import c_oracle as co
