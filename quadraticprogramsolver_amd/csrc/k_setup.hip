@@ -114,16 +114,19 @@ template <typename T>
 __global__ void k_make_PI(int n, int NP, const T* __restrict__ P, T sigma, T* __restrict__ PI) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= NP) return;
+    P += (int64_t)blockIdx.z * NP * NP; PI += (int64_t)blockIdx.z * NP * NP;
     T v = T(0);
     if (i < n && j < n) v = P[(int64_t)i * NP + j] + (i == j ? sigma : T(0));   // LinearSystemSolvers.jl:113
     else if (i == j) v = T(1);
     PI[(int64_t)i * NP + j] = v;
 }
 template <typename T>
-__global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restrict__ AA, T rho, T* __restrict__ M) {
+__global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restrict__ AA, T rho, T* __restrict__ M,
+                             const double* __restrict__ rho_arr) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= NP || j > (i | 63)) return;                                          // lower tiles incl. whole diagonal tile
-    const int64_t o = (int64_t)i * NP + j;
+    if (rho_arr) rho = (T)rho_arr[blockIdx.z];                                    // batched: every QP has its own rho
+    const int64_t o = (int64_t)blockIdx.z * NP * NP + (int64_t)i * NP + j;
     // AA holds the lower tiles of A'A; inside a diagonal tile both halves are present
     M[o] = PI[o] + rho * AA[o];                                                   // LinearSystemSolvers.jl:114 / :128
 }
@@ -133,9 +136,10 @@ __global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restri
 // the panel is factorised with wave64 shuffles only (no LDS, no barrier); the finished panel is then published through
 // LDS and the waves to its right apply the rank-16 update.  4 panels => 8 barriers per block instead of 128.
 template <typename T>
-__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail) {
+__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail, int64_t sM) {
     __shared__ T Lp[64][17];
     const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    M += (int64_t)blockIdx.x * sM; fail += blockIdx.x;                            // batched: one workgroup per QP
     T* blk = M + (int64_t)kb * 64 * ld + kb * 64;
     T a[16];
 #pragma unroll
@@ -183,10 +187,11 @@ __global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, 
 // Inverses of ALL 64 x 64 diagonal blocks of L in one launch (blockIdx.x = block): forward elimination on the identity,
 // row i accumulates -sum_{p<i} L[i][p] X[p][:] and is scaled by 1/L[i][i] when k reaches i.  Off the Cholesky critical path.
 template <typename T>
-__global__ __launch_bounds__(256) void k_inv64(const T* __restrict__ L, int64_t ld, T* __restrict__ dinv) {
+__global__ __launch_bounds__(256) void k_inv64(const T* __restrict__ L, int64_t ld, T* __restrict__ dinv, int64_t sM, int64_t sD) {
     __shared__ T Ls[64][65];
     __shared__ T rowk[64];
     const int kb = blockIdx.x;
+    L += (int64_t)blockIdx.y * sM; dinv += (int64_t)blockIdx.y * sD;
     const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const T* blk = L + (int64_t)kb * 64 * ld + kb * 64;
 #pragma unroll
@@ -217,10 +222,11 @@ __global__ __launch_bounds__(256) void k_inv64(const T* __restrict__ L, int64_t 
 // Panel solve X * L11' = A21 (in place), one thread per row of A21: x_j = (a_j - sum_{k<j} x_k L11[j][k]) / L11[j][j].
 // L11 sits in LDS and every lane reads the same element at the same time (broadcast).
 template <typename T>
-__global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld, int kb, int nrows) {
+__global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld, int kb, int nrows, int64_t sM) {
     __shared__ T Ls[64][65];
     __shared__ T rdiag[64];
     const int t = threadIdx.x;
+    M += (int64_t)blockIdx.y * sM;
     const T* L11 = M + (int64_t)kb * 64 * ld + kb * 64;
     for (int r = 0; r < 64; ++r) Ls[r][t] = L11[(int64_t)r * ld + t];
     __syncthreads();
@@ -245,9 +251,10 @@ __global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld
 
 // S lower <- L lower with the 64-blocks on the diagonal replaced by their inverses; S upper <- 0
 template <typename T>
-__global__ void k_init_sweep(int NP, const T* __restrict__ L, const T* __restrict__ dinv, T* __restrict__ S) {
+__global__ void k_init_sweep(int NP, const T* __restrict__ L, const T* __restrict__ dinv, T* __restrict__ S, int64_t sD) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= NP) return;
+    L += (int64_t)blockIdx.z * NP * NP; S += (int64_t)blockIdx.z * NP * NP; dinv += (int64_t)blockIdx.z * sD;
     T v = T(0);
     if ((i >> 6) == (j >> 6)) v = dinv[(int64_t)(i >> 6) * 4096 + (i & 63) * 64 + (j & 63)];
     else if (j < i) v = L[(int64_t)i * NP + j];
@@ -258,6 +265,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_mirror(int NP, T* __restrict__ S) {
     const int bj = blockIdx.x, bi = blockIdx.y;
     if (bj > bi) return;
+    S += (int64_t)blockIdx.z * NP * NP;
     __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) tile[r][tx] = S[(int64_t)(bi * 64 + r) * NP + bj * 64 + tx];
@@ -288,62 +296,74 @@ void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda,
     else hipLaunchKernelGGL((k_gemm<T, false, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
 }
 
-template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI) {
-    hipLaunchKernelGGL((k_make_PI<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, n, NP, P, sigma, PI);
+template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI, int batch) {
+    hipLaunchKernelGGL((k_make_PI<T>), dim3((NP + 255) / 256, NP, batch), dim3(256), 0, st, n, NP, P, sigma, PI);
 }
-template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M) {
-    hipLaunchKernelGGL((k_assemble_M<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, NP, PI, AA, rho, M);
+template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M, int batch, const double* rho_arr) {
+    hipLaunchKernelGGL((k_assemble_M<T>), dim3((NP + 255) / 256, NP, batch), dim3(256), 0, st, NP, PI, AA, rho, M, rho_arr);
 }
 
-template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev) {
-    (void)hipMemsetAsync(fail_dev, 0, sizeof(int), st);
+// batch > 1: the same factorisation for `batch` matrices NP*NP apart (dinv blocks (NP/64)*4096 apart, fail flags 1 apart):
+// every launch carries all QPs, so the launch-latency-bound panel chain is paid once instead of `batch` times.
+template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch) {
+    (void)hipMemsetAsync(fail_dev, 0, sizeof(int) * batch, st);
     const int nblk = NP / 64;
+    const int64_t sM = (int64_t)NP * NP, sD = (int64_t)nblk * 4096;
     for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL((k_potrf64<T>), dim3(1), dim3(256), 0, st, M, (int64_t)NP, kb, fail_dev);
+        hipLaunchKernelGGL((k_potrf64<T>), dim3(batch), dim3(256), 0, st, M, (int64_t)NP, kb, fail_dev, sM);
         const int rem = NP - (kb + 1) * 64;
         if (rem <= 0) break;
         // L21 = A21 * inv(L11)'  by forward substitution, one thread per row
-        hipLaunchKernelGGL((k_trsm_panel<T>), dim3(rem / 64), dim3(64), 0, st, M, (int64_t)NP, kb, rem);
+        hipLaunchKernelGGL((k_trsm_panel<T>), dim3(rem / 64, batch), dim3(64), 0, st, M, (int64_t)NP, kb, rem, sM);
         // A22 -= L21 * L21'  (lower tiles only)
         T* A21 = M + (int64_t)(kb + 1) * 64 * NP + kb * 64;
         T* A22 = M + (int64_t)(kb + 1) * 64 * NP + (kb + 1) * 64;
-        gemm<T>(st, rem, rem, 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true);
+        gemm<T>(st, rem, rem, 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true, batch, sM, sM, sM);
     }
-    hipLaunchKernelGGL((k_inv64<T>), dim3(nblk), dim3(256), 0, st, M, (int64_t)NP, dinv);
+    hipLaunchKernelGGL((k_inv64<T>), dim3(nblk, batch), dim3(256), 0, st, M, (int64_t)NP, dinv, sM, sD);
 }
 
-template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp) {
-    hipLaunchKernelGGL((k_init_sweep<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, NP, L, dinv, S);
+// batch > 1: L, S and tmp hold `batch` matrices NP*NP apart.  The doubling GEMMs are batched over the QPs (blockIdx.z) and
+// looped over the pairs of a level on the host (pairs x QPs would need two batch strides).
+template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp, int batch) {
+    const int64_t sM = (int64_t)NP * NP, sD = (int64_t)(NP / 64) * 4096;
+    hipLaunchKernelGGL((k_init_sweep<T>), dim3((NP + 255) / 256, NP, batch), dim3(256), 0, st, NP, L, dinv, S, sD);
     // recursive doubling: inv([L00 0; L10 L11]) = [inv00 0; -inv11 L10 inv00, inv11]
     for (int s = 64; s < nb; s *= 2) {
         const int64_t pstride = (int64_t)2 * s * (NP + 1);
         int nfull = 0;
         while ((nfull + 1) * 2 * s <= NP) ++nfull;
-        if (nfull > 0) {
+        if (nfull > 0 && batch == 1) {
             // tmp10 = L10 * inv00 ; S10 = -inv11 * tmp10     (batched over the pairs)
             gemm<T>(st, s, s, s, T(1), L + (int64_t)s * NP, NP, true, S, NP, false, T(0), tmp + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride, 1);
             gemm<T>(st, s, s, s, T(-1), S + (int64_t)s * (NP + 1), NP, true, tmp + (int64_t)s * NP, NP, false, T(0), S + (int64_t)s * NP, NP, false, nfull, pstride, pstride, pstride, 2);
+        } else {
+            for (int p = 0; p < nfull; ++p) {   // batched over the QPs, one pair per launch
+                const int64_t o = (int64_t)p * pstride;
+                gemm<T>(st, s, s, s, T(1), L + o + (int64_t)s * NP, NP, true, S + o, NP, false, T(0), tmp + o + (int64_t)s * NP, NP, false, batch, sM, sM, sM, 1);
+                gemm<T>(st, s, s, s, T(-1), S + o + (int64_t)s * (NP + 1), NP, true, tmp + o + (int64_t)s * NP, NP, false, T(0), S + o + (int64_t)s * NP, NP, false, batch, sM, sM, sM, 2);
+            }
         }
         const int o = nfull * 2 * s;
         const int s2 = NP - o - s;
         if (s2 > 0) {   // ragged last pair: second block has s2 < s rows
             const T* L10 = L + (int64_t)(o + s) * NP + o;
             T* t10 = tmp + (int64_t)(o + s) * NP + o;
-            gemm<T>(st, s2, s, s, T(1), L10, NP, true, S + (int64_t)o * (NP + 1), NP, false, T(0), t10, NP, false, 1, 0, 0, 0, 1);
-            gemm<T>(st, s2, s, s2, T(-1), S + (int64_t)(o + s) * (NP + 1), NP, true, t10, NP, false, T(0), S + (int64_t)(o + s) * NP + o, NP, false, 1, 0, 0, 0, 2);
+            gemm<T>(st, s2, s, s, T(1), L10, NP, true, S + (int64_t)o * (NP + 1), NP, false, T(0), t10, NP, false, batch, sM, sM, sM, 1);
+            gemm<T>(st, s2, s, s2, T(-1), S + (int64_t)(o + s) * (NP + 1), NP, true, t10, NP, false, T(0), S + (int64_t)(o + s) * NP + o, NP, false, batch, sM, sM, sM, 2);
         }
     }
-    hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64), dim3(256), 0, st, NP, S);
+    hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64, batch), dim3(256), 0, st, NP, S);
 }
 
 #define INST(T)                                                                                                        \
     template void import_colmajor<T>(hipStream_t, const double*, int64_t, int, int, T*, int64_t);                      \
     template void gemm<T>(hipStream_t, int, int, int, T, const T*, int64_t, bool, const T*, int64_t, bool, T, T*, int64_t, \
                           bool, int, int64_t, int64_t, int64_t, int);                                                  \
-    template void make_PI<T>(hipStream_t, int, int, const T*, T, T*);                                                  \
-    template void assemble_M<T>(hipStream_t, int, const T*, const T*, T, T*);                                          \
-    template void cholesky<T>(hipStream_t, int, T*, T*, int*);                                                         \
-    template void build_sweep_matrix<T>(hipStream_t, int, int, const T*, const T*, T*, T*);
+    template void make_PI<T>(hipStream_t, int, int, const T*, T, T*, int);                                             \
+    template void assemble_M<T>(hipStream_t, int, const T*, const T*, T, T*, int, const double*);                      \
+    template void cholesky<T>(hipStream_t, int, T*, T*, int*, int);                                                    \
+    template void build_sweep_matrix<T>(hipStream_t, int, int, const T*, const T*, T*, T*, int);
 INST(double)
 INST(float)
 #undef INST

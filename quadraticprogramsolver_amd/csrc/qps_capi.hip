@@ -365,7 +365,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         part_tiles = gemv_cols_tiles(MP);
         const int64_t nn = (int64_t)NP * NP, c = count;
         A = dalloc<T>(c * MP * NP); P = dalloc<T>(c * nn); PI = dalloc<T>(c * nn); AA = dalloc<T>(c * nn); M = dalloc<T>(c * nn);
-        S = dalloc<T>(c * nn); tmp = dalloc<T>(nn); dinv = dalloc<T>((int64_t)(NP / 64) * 4096);
+        S = dalloc<T>(c * nn); tmp = dalloc<T>(c * nn); dinv = dalloc<T>(c * (int64_t)(NP / 64) * 4096);
         q = dalloc<T>(c * NP); l = dalloc<T>(c * MP); u = dalloc<T>(c * MP);
         x = dalloc<T>(c * NP); xp = dalloc<T>(c * NP); xres = dalloc<T>(c * NP); xx = dalloc<T>(c * NP); tt = dalloc<T>(c * NP);
         yv = dalloc<T>(c * NP); Px = dalloc<T>(c * NP); Aty = dalloc<T>(c * NP); z = dalloc<T>(c * MP); y = dalloc<T>(c * MP);
@@ -415,8 +415,20 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             gemm<T>(st, NP, NP, MP, T(1), Ab, NP, false, Ab, NP, false, T(0), AAb, NP, true);
         }
         assemble_M<T>(st, NP, PIb, AAb, (T)rho, Mb);
-        cholesky<T>(st, NP, Mb, dinv, fail + b);
-        build_sweep_matrix<T>(st, NP, nb, Mb, dinv, Sb, tmp);
+        T* dinvb = dinv + (int64_t)b * (NP / 64) * 4096;
+        cholesky<T>(st, NP, Mb, dinvb, fail + b);
+        build_sweep_matrix<T>(st, NP, nb, Mb, dinvb, Sb, tmp + b * nn);
+    }
+    // all QPs at once (same rho): every launch of the panel chain carries the whole batch
+    void factorize_all(double rho, double sigma, bool rebuild, const double* rho_arr = nullptr) {
+        const int64_t nn = (int64_t)NP * NP;
+        if (rebuild) {
+            make_PI<T>(st, (int)n, NP, P, (T)sigma, PI, count);
+            gemm<T>(st, NP, NP, MP, T(1), A, NP, false, A, NP, false, T(0), AA, NP, true, count, (int64_t)MP * NP, (int64_t)MP * NP, nn);
+        }
+        assemble_M<T>(st, NP, PI, AA, (T)rho, M, count, rho_arr);
+        cholesky<T>(st, NP, M, dinv, fail, count);
+        build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp, count);
     }
     void check_fail(const std::vector<int>& which) {
         if (which.empty()) return;
@@ -450,7 +462,9 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         if ((int)fac_rho.size() != count) fac_rho.assign(count, -1.0);
         std::vector<int> todo;
         for (int b = 0; b < count; ++b)                                                             // SolveQuadraticProgram.jl:36
-            if (rebuild || fac_rho[b] != p.rho || fac_nb != nb) { factorize_one(b, p.rho, sigma, rebuild); todo.push_back(b); }
+            if (rebuild || fac_rho[b] != p.rho || fac_nb != nb) todo.push_back(b);
+        if ((int)todo.size() == count) factorize_all(p.rho, sigma, rebuild);
+        else for (int b : todo) factorize_one(b, p.rho, sigma, rebuild);
         check_fail(todo);
         have_AA = true; fac_sigma = sigma; fac_nb = nb;
         for (int b : todo) fac_rho[b] = p.rho;
@@ -474,9 +488,14 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                     }
             if (!changed.empty()) {
                 const double ta = now_s();
+                const bool together = (int)changed.size() * 2 >= count;   // most QPs switch at the same check: one batched refactor
+                if (together) {
+                    push_state(rho, rhorho, active);                      // d_rho must hold the new values before assembly
+                    factorize_all(0.0, sigma, false, d_rho);
+                    for (int b = 0; b < count; ++b) fac_rho[b] = rho[b];
+                }
                 for (int b : changed) {
-                    factorize_one(b, rho[b], sigma, false);
-                    fac_rho[b] = rho[b];
+                    if (!together) { factorize_one(b, rho[b], sigma, false); fac_rho[b] = rho[b]; }
                     if (rhs_slabs > 0) {   // slabs of A'(rho z - y) depend on rho: rebuild them for this QP (slab 0 = the sum, rest 0)
                         T* pb_ = part + (int64_t)b * slabs * NP;
                         gemv_cols_partial<T>(st, A + (int64_t)b * MP * NP, NP, z + (int64_t)b * MP, y + (int64_t)b * MP, (T)rho[b], T(-1), part_tmp, NP, MP, NP);
@@ -484,7 +503,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                         if (slabs > 1) HIPC(hipMemsetAsync(pb_ + NP, 0, sizeof(T) * (size_t)(slabs - 1) * NP, st));
                     }
                 }
-                check_fail(changed);
+                if (together) check_fail(all); else check_fail(changed);
                 push_state(rho, rhorho, active);
                 const double dt = (now_s() - ta) / changed.size();
                 for (int b : changed) tref[b] += dt;

@@ -108,16 +108,17 @@ void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda,
 // after the tile's last row): structurally zero k-tiles are skipped.
 
 // M = PI + rho * AA (lower triangle incl. diagonal tiles; NP x NP)   (LinearSystemSolvers.jl:114,128)
-template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M);
+template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M, int batch = 1,
+                                      const double* rho_arr = nullptr);   // rho_arr: per-QP rho (device) for a batch
 // PI = P + sigma I on the n x n part, identity on the padding diagonal (keeps the padded factor well defined)
-template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI);
+template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI, int batch = 1);
 
 // Blocked right-looking Cholesky of the NP x NP row-major matrix M (lower), in place.  dinv receives the inverses of
 // the 64 x 64 diagonal blocks (NP/64 blocks of 64*64).  fail_dev: int32, 0 or 1+index of the failing pivot.
-template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev);
+template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch = 1);   // batch: matrices NP*NP apart
 
 // Build the sweep matrix S from L (lower of M) and the 64-block inverses: diagonal nb-blocks inverted by recursive
 // doubling, then mirrored into the upper triangle.  tmp: NP x NP scratch.
-template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp);
+template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp, int batch = 1);
 
 }  // namespace qps
