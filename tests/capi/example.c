@@ -1,0 +1,56 @@
+/* Pure-C consumer of the drop-in boundary (include/qps.h): no Python, no HIP headers, no C++.
+ * Solves   min 1/2 x'Px + q'x  s.t. l <= Ax <= u   for a small diagonal-box problem with a known answer
+ * (x* = clamp(-q./p, l, u)), once through qps_solve and once through the literal plugin pair
+ * qps_linsys_init / qps_linsys_solve, and prints the result.  Exit code 0 = all checks passed. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "qps.h"
+
+int main(void) {
+    enum { N = 6 };
+    double P[N * N] = {0}, A[N * N] = {0}, q[N], l[N], u[N], x[N] = {0}, xstar[N];
+    for (int i = 0; i < N; ++i) {
+        const double p = 1.0 + 0.5 * i;
+        P[i + i * N] = p; A[i + i * N] = 1.0;                       /* column-major, like a Julia Matrix{Float64} */
+        q[i] = (i % 2 ? 1.0 : -1.0) * (1.0 + i); l[i] = -0.75; u[i] = 0.5;
+        double t = -q[i] / p; xstar[i] = t > u[i] ? u[i] : (t < l[i] ? l[i] : t);
+    }
+    if (qps_device_count() < 1) { fprintf(stderr, "no HIP device: %s\n", qps_version()); return 2; }
+    qps_handle h = NULL;
+    int rc = qps_create_dense(N, N, P, N, A, N, q, l, u, QPS_F64, 0, &h);
+    if (rc != QPS_OK) { fprintf(stderr, "create failed: %s\n", qps_last_error(NULL)); return 1; }
+    qps_params prm; qps_info info;
+    qps_default_params(&prm);
+    prm.numIterations = 50000; prm.epsAbs = 1e-7; prm.epsRel = 1e-7; prm.rho = 0.1; prm.adptRho = 1;   /* RunTests.jl:50-54 */
+    rc = qps_solve(h, x, &prm, &info);
+    if (rc != QPS_OK) { fprintf(stderr, "solve failed: %s\n", qps_last_error(h)); return 1; }
+    double dev = 0.0;
+    for (int i = 0; i < N; ++i) dev = fmax(dev, fabs(x[i] - xstar[i]));
+    printf("flag=%d iterations=%d max|x-x*|=%.3e rho_final=%g\n", info.convFlag, info.iterations, dev, info.rhoFinal);
+    int ok = (info.convFlag == QPS_CONV_PRIM_DUAL || info.convFlag == QPS_CONV_ADMM) && dev <= 1e-5;
+    /* the plugin pair: x~ solves (P + sigma I + rho A'A) x~ = sigma x - q + A'(rho z - y), z~ = A x~ */
+    double z[N], y[N], xx[N], zz[N], xin[N];
+    for (int i = 0; i < N; ++i) { xin[i] = 0.1 * i; z[i] = 0.2 - 0.05 * i; y[i] = 0.03 * i; }
+    rc = qps_linsys_init(h, 0.7, 1e-6, QPS_LINSYS_CHOLESKY, 0);
+    if (rc == QPS_OK) rc = qps_linsys_solve(h, xin, z, y, 0.7, 1e-6, 0, xx, zz);
+    if (rc != QPS_OK) { fprintf(stderr, "linsys failed: %s\n", qps_last_error(h)); return 1; }
+    double res = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double lhs = (P[i + i * N] + 1e-6 + 0.7) * xx[i];                 /* A = I, P diagonal */
+        const double rhs = 1e-6 * xin[i] - q[i] + (0.7 * z[i] - y[i]);
+        res = fmax(res, fabs(lhs - rhs)); res = fmax(res, fabs(zz[i] - xx[i]));
+    }
+    printf("plugin pair residual=%.3e\n", res);
+    ok = ok && res <= 1e-12;
+    /* error path: a non-positive-definite problem must be reported, not hidden */
+    qps_handle hb = NULL;
+    for (int i = 0; i < N; ++i) P[i + i * N] = -1.0;
+    rc = qps_create_dense(N, N, P, N, A, N, q, l, u, QPS_F64, 0, &hb);
+    if (rc == QPS_OK) { prm.rho = 1e-3; prm.adptRho = 0; rc = qps_solve(hb, x, &prm, NULL); printf("indefinite P -> status %d (%s)\n", rc, qps_last_error(hb)); ok = ok && rc == QPS_ERR_FACTORIZATION; }
+    qps_destroy(hb);
+    qps_destroy(h);
+    printf(ok ? "C ABI example OK\n" : "C ABI example FAILED\n");
+    return ok ? 0 : 1;
+}

@@ -395,3 +395,17 @@ def test_runtests_sweep(gpu, c_oracle, np_oracle, pc):
                 assert prim <= 1e-5 * max(1.0, np.abs(z).max()) and dual <= 1e-4 and comp <= 1e-4
             checked += 1
     assert checked >= 10
+
+
+def test_pure_c_consumer_of_the_abi(gpu, tmp_path):
+    """The boundary is a C ABI: a C program built with gcc against include/qps.h and linked to libqps_hip.so (no Python,
+    no HIP headers) solves a known-answer problem, drives the plugin pair and sees the factorisation error code."""
+    import os, subprocess
+    from quadraticprogramsolver_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "capi_example")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "capi", "example.c"),
+                           "-o", exe, "-L", libdir, "-lqps_hip", "-lm", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0 and "C ABI example OK" in out.stdout, out.stdout
