@@ -409,3 +409,32 @@ def test_pure_c_consumer_of_the_abi(gpu, tmp_path):
                            "-o", exe, "-L", libdir, "-lqps_hip", "-lm", f"-Wl,-rpath,{libdir}"])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert out.returncode == 0 and "C ABI example OK" in out.stdout, out.stdout
+
+
+def test_concurrent_handles_from_two_host_threads(gpu, c_oracle):
+    """Threading contract of include/qps.h: distinct handles (each with its own stream) may be driven from distinct host
+    threads at the same time.  ctypes releases the GIL inside the foreign call, so the two solves really overlap."""
+    import threading
+    cases = [GenerateDenseBenchmarkQP(300, 500, stream=50, feasible=True), GenerateDenseBenchmarkQP(700, 900, stream=51, feasible=True)]
+    results = [None, None]
+
+    def work(k):
+        P, q, A, l, u = cases[k]
+        with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+            outs = []
+            for rep in range(3):
+                x = np.zeros(P.shape[0]); info = {}
+                flag = prob.solve(x, info=info, **REF_KW)
+                outs.append((x, int(flag), info["iterations"]))
+            results[k] = outs
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for k in range(2):
+        assert results[k] is not None
+        xo, io = c_oracle.solve(*cases[k], numIterations=50000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
+        for x, flag, its in results[k]:
+            assert flag == io["convFlag"] and its == io["iterations"] and np.abs(x - xo).max() <= ABS_DEV_THR
