@@ -277,9 +277,9 @@ template <typename T> struct DenseSolver : SolverBase {
                 sweeps();                                                                           // :137
                 if (check) HIPC(hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long), st));
                 {
-                    // level 1 samples the dominant kernel on every 10th iteration only (an event pair per launch costs ~7 %
-                    // of the loop); level 2 brackets every launch of every kernel
-                    const int lvl = (prof.level == 1 && (ii % 10 != 3) && !check) ? 3 : 1;
+                    // level 1 samples the dominant kernel on every 50th iteration only (an event pair per launch costs ~7 % of
+                    // the loop, one in ten still ~3 %); level 2 brackets every launch of every kernel
+                    const int lvl = (prof.level == 1 && (check || ii % 50 != 38)) ? 3 : 1;   // mid-chunk sample of the plain variant only
                     ProfScope ps(prof, check ? cat_passchk : cat_pass, lvl);
                     apass<T>(st, check, A, NP, NP, MP, xx, x, xp, z, y, l, u, (T)alpha, (T)rho, part, part2, NP, scratch);
                 }
