@@ -151,6 +151,38 @@ int32_t qps_kernel_times(qps_handle h, qps_kernel_time *out, int32_t cap, int32_
  * 2 = bracket every loop kernel (diagnostic).  Setting the level also resets the accumulated times. */
 int32_t qps_set_profiling(qps_handle h, int32_t on);
 
+/* ---- The reference's second solver form (ProxQP.jl):  min 1/2 x'Px + q'x  s.t.  A x = b,  C x <= d ---------------------------
+ * qps_proxqp_create_dense  == the data half of  ProxQP(mP, vQ, mA, vB, mC, vD [, vX, vY, vZ, vS])        ProxQP.jl:36,73
+ * qps_proxqp_init_kkt      == the initialisation of the 6-argument constructor (x, y from the equality-constrained KKT
+ *                             system, s = max(d - C x, 0), z = 0)                                        ProxQP.jl:80-89
+ * qps_proxqp_set_state     == the explicit vX, vY, vZ, vS of the 10-argument constructor                 ProxQP.jl:36
+ * qps_proxqp_solve         == SolveQuadraticProgram!(sQpProb; numIterations, ϵAbs, ϵRel, numItrConv, ρ, σ, adptΡ, τ) -> dReport
+ *                             (always runs numIterations: the reference's `break` is commented out)      ProxQP.jl:118-173
+ * qps_proxqp_get_state     == reading sQpProb.vX / vY / vZ / vS afterwards
+ * All matrices column-major (Julia Matrix{Float64}); numEq or numInEq may be 0.  Same handle type, qps_destroy frees it. */
+typedef struct {
+    int32_t numIterations;   /* 2000 */
+    int32_t numItrConv;      /* 50 */
+    int32_t adptRho;         /* adptΡ, default 1 */
+    int32_t reserved;
+    double epsAbs;           /* ϵAbs 1e-7 */
+    double epsRel;           /* ϵRel 1e-6 */
+    double rho;              /* ρ 1e2 */
+    double sigma;            /* σ 1e-2 */
+    double tau;              /* τ 10 */
+} qps_proxqp_params;
+typedef struct {             /* dReport (ProxQP.jl:127): "Converged", "Iterations", "ρ", "σ", "PrimalResidual", "DualResidual" */
+    int32_t converged; int32_t iterations; double rho, sigma, resPrim, resDual;
+} qps_proxqp_report;
+int32_t qps_proxqp_default_params(qps_proxqp_params *p);
+int32_t qps_proxqp_create_dense(int64_t n, int64_t numEq, int64_t numInEq, const double *P, int64_t ldp, const double *q,
+                                const double *A, int64_t lda, const double *b, const double *C, int64_t ldc, const double *d,
+                                int32_t dtype, int32_t device, qps_handle *out);
+int32_t qps_proxqp_init_kkt(qps_handle h);
+int32_t qps_proxqp_set_state(qps_handle h, const double *x, const double *y, const double *z, const double *s);
+int32_t qps_proxqp_get_state(qps_handle h, double *x, double *y, double *z, double *s);
+int32_t qps_proxqp_solve(qps_handle h, const qps_proxqp_params *params, qps_proxqp_report *report);
+
 int32_t qps_destroy(qps_handle h);
 /* Human-readable description of the last failure on this handle (or of the last failed create when h == NULL). */
 const char *qps_last_error(qps_handle h);

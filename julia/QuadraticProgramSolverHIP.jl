@@ -111,3 +111,43 @@ function (::HipCholT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, 
         h, vX, vZ, vY, ρ, σ, Int32(changedΡ), vXX, vZZ), h)
     return
 end
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The second solver form (ProxQP.jl):  min 1/2 x'Px + q'x  s.t.  A x = b,  C x <= d   -- device version (dense inputs).
+# Mirrors `ProxQP(mP, vQ, mA, vB, mC, vD)` (ProxQP.jl:73-93) and `SolveQuadraticProgram!(sQpProb; ...)` (:118-173).
+# ---------------------------------------------------------------------------------------------------------------------
+struct QpsProxQpParams
+    numIterations::Int32; numItrConv::Int32; adptRho::Int32; reserved::Int32
+    epsAbs::Float64; epsRel::Float64; rho::Float64; sigma::Float64; tau::Float64
+end
+mutable struct QpsProxQpReport
+    converged::Int32; iterations::Int32; rho::Float64; sigma::Float64; resPrim::Float64; resDual::Float64
+    QpsProxQpReport() = new(0, 0, 0.0, 0.0, 0.0, 0.0)
+end
+mutable struct ProxQPHip{T <: AbstractFloat}
+    h  :: Ptr{Cvoid}
+    vX :: Vector{T}; vY :: Vector{T}; vZ :: Vector{T}; vS :: Vector{T}     # same field names as ProxQP.jl:9-18
+    dataDim :: Int; numEq :: Int; numInEq :: Int
+end
+function ProxQPHip(mP :: Matrix{Float64}, vQ :: Vector{Float64}, mA :: Matrix{Float64}, vB :: Vector{Float64}, mC :: Matrix{Float64}, vD :: Vector{Float64})
+    n, me, mi = size(mP, 1), size(mA, 1), size(mC, 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve mP vQ mA vB mC vD _check(ccall((:qps_proxqp_create_dense, LIBQPS), Int32,
+        (Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Int32, Ref{Ptr{Cvoid}}),
+        n, me, mi, mP, n, vQ, mA, max(me, 1), vB, mC, max(mi, 1), vD, Int32(0), Int32(0), h))
+    _check(ccall((:qps_proxqp_init_kkt, LIBQPS), Int32, (Ptr{Cvoid},), h[]), h[])          # ProxQP.jl:80-89 on the device
+    s = ProxQPHip{Float64}(h[], zeros(n), zeros(max(me, 1)), zeros(max(mi, 1)), zeros(max(mi, 1)), n, me, mi)
+    finalizer(x -> ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), x.h), s)
+    return s
+end
+function SolveQuadraticProgram!(sQpProb :: ProxQPHip{Float64}; numIterations = 2000, ϵAbs = 1e-7, ϵRel = 1e-6, numItrConv = 50,
+                                ρ = 1e2, σ = 1e-2, adptΡ :: Bool = true, τ = 10.0)
+    prm = QpsProxQpParams(numIterations, numItrConv, adptΡ, 0, ϵAbs, ϵRel, ρ, σ, τ)
+    rep = QpsProxQpReport()
+    _check(ccall((:qps_proxqp_solve, LIBQPS), Int32, (Ptr{Cvoid}, Ref{QpsProxQpParams}, Ref{QpsProxQpReport}), sQpProb.h, Ref(prm), rep), sQpProb.h)
+    GC.@preserve sQpProb _check(ccall((:qps_proxqp_get_state, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                                      sQpProb.h, sQpProb.vX, sQpProb.vY, sQpProb.vZ, sQpProb.vS), sQpProb.h)
+    return Dict{String, Real}("Converged" => rep.converged != 0, "Iterations" => rep.iterations, "ρ" => rep.rho, "σ" => rep.sigma,
+                              "PrimalResidual" => rep.resPrim, "DualResidual" => rep.resDual)     # ProxQP.jl:127
+end

@@ -6,9 +6,10 @@ from .generator import (GenerateDenseBenchmarkQP, GenerateRandomQP, GenerateSpar
 from .solver import (ConvergenceFlag, HipCg, HipCgInit, HipChol, HipCholF32, HipCholF32Init, HipCholInit,
                      LinearSolverMode, QuadraticProgram, QuadraticProgramBatch, SolveQuadraticProgram, SolveQuadraticProgram_b,
                      SolveQuadraticProgramInplace)
+from .proxqp import ProxQP, SolveQuadraticProgramProxQP
 from ._lib import QpsError, QpsLibraryError
 
 __all__ = ["GenerateRandomQP", "GenerateDenseBenchmarkQP", "GenerateSparseBenchmarkQP", "ProblemClass", "make_rng",
            "sprandn", "SaveQpModel", "LoadQpModel", "ConvergenceFlag", "LinearSolverMode", "QuadraticProgram", "QuadraticProgramBatch", "SolveQuadraticProgram",
            "SolveQuadraticProgramInplace", "SolveQuadraticProgram_b", "HipCholInit", "HipChol", "HipCgInit", "HipCg",
-           "HipCholF32Init", "HipCholF32", "QpsError", "QpsLibraryError"]
+           "HipCholF32Init", "HipCholF32", "ProxQP", "SolveQuadraticProgramProxQP", "QpsError", "QpsLibraryError"]

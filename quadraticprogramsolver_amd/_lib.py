@@ -19,6 +19,8 @@ EXPORTED_SYMBOLS = [
     "qps_default_params", "qps_device_count", "qps_create_dense", "qps_create_csc", "qps_solve", "qps_get_dual",
     "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
     "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
+    "qps_proxqp_default_params", "qps_proxqp_create_dense", "qps_proxqp_init_kkt", "qps_proxqp_set_state", "qps_proxqp_get_state",
+    "qps_proxqp_solve",
 ]
 
 QPS_OK = 0
@@ -59,6 +61,16 @@ class QpsInfo(C.Structure):
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class QpsProxQpParams(C.Structure):
+    _fields_ = [("numIterations", C.c_int32), ("numItrConv", C.c_int32), ("adptRho", C.c_int32), ("reserved", C.c_int32),
+                ("epsAbs", C.c_double), ("epsRel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double), ("tau", C.c_double)]
+
+
+class QpsProxQpReport(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rho", C.c_double), ("sigma", C.c_double),
+                ("resPrim", C.c_double), ("resDual", C.c_double)]
 
 
 class QpsKernelTime(C.Structure):
@@ -107,6 +119,12 @@ def lib() -> C.CDLL:
     L.qps_solve_batch.argtypes = [hp, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo)]
     L.qps_kernel_times.argtypes = [hp, C.POINTER(QpsKernelTime), i32, C.POINTER(i32)]
     L.qps_set_profiling.argtypes = [hp, i32]
+    L.qps_proxqp_default_params.argtypes = [C.POINTER(QpsProxQpParams)]
+    L.qps_proxqp_create_dense.argtypes = [i64, i64, i64, dp, i64, dp, dp, i64, dp, dp, i64, dp, i32, i32, C.POINTER(hp)]
+    L.qps_proxqp_init_kkt.argtypes = [hp]
+    L.qps_proxqp_set_state.argtypes = [hp, dp, dp, dp, dp]
+    L.qps_proxqp_get_state.argtypes = [hp, dp, dp, dp, dp]
+    L.qps_proxqp_solve.argtypes = [hp, C.POINTER(QpsProxQpParams), C.POINTER(QpsProxQpReport)]
     L.qps_destroy.argtypes = [hp]
     L.qps_last_error.argtypes = [hp]
     L.qps_last_error.restype = C.c_char_p

@@ -5,6 +5,7 @@
 // There is NO CPU fallback: without a HIP device every entry point fails with QPS_ERR_NO_DEVICE.
 #include "qps_internal.h"
 #include "qps_kernels.h"
+#include "qps_proxqp.h"
 
 using namespace qps;
 
@@ -574,7 +575,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
 // =================================================================================================================
 // handle plumbing
 // =================================================================================================================
-struct Handle { SolverBase* impl = nullptr; std::vector<SolverBase*> batch; BatchSolverBase* fused_batch = nullptr; int64_t n = 0, m = 0; std::string err; };
+struct Handle { SolverBase* impl = nullptr; std::vector<SolverBase*> batch; BatchSolverBase* fused_batch = nullptr; ProxQpBase* proxqp = nullptr; int64_t n = 0, m = 0; std::string err; };
 
 int fail_with(Handle* h, int code, const std::string& msg) {
     g_last_error = msg;
@@ -838,11 +839,70 @@ QPS_API int32_t qps_kernel_times(qps_handle hh, qps_kernel_time* out, int32_t ca
     return QPS_OK;
 }
 
+QPS_API int32_t qps_proxqp_default_params(qps_proxqp_params* p) {
+    if (!p) return QPS_ERR_BAD_ARGUMENT;
+    memset(p, 0, sizeof(*p));
+    p->numIterations = 2000; p->epsAbs = 1e-7; p->epsRel = 1e-6; p->numItrConv = 50; p->rho = 1e2; p->sigma = 1e-2; p->adptRho = 1; p->tau = 10.0;   // ProxQP.jl:118
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_proxqp_create_dense(int64_t n, int64_t me, int64_t mi, const double* P, int64_t ldp, const double* q, const double* A,
+                                        int64_t lda, const double* b, const double* C, int64_t ldc, const double* d, int32_t dtype,
+                                        int32_t device, qps_handle* out) {
+    if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
+    *out = nullptr;
+    if (n <= 0 || me < 0 || mi < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1, numEq >= 0, numInEq >= 0");
+    if (n > (1 << 16) || me + mi > (1 << 20)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "problem too large");
+    if (!P || !q || (me > 0 && (!A || !b)) || (mi > 0 && (!C || !d))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
+    if (ldp < n || (me > 0 && lda < me) || (mi > 0 && ldc < mi)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "leading dimension smaller than the row count");
+    if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
+    for (int64_t j = 0; j < n; ++j) {
+        if (!all_finite(P + j * ldp, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P contains NaN/Inf");
+        if (me > 0 && !all_finite(A + j * lda, me, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "A contains NaN/Inf");
+        if (mi > 0 && !all_finite(C + j * ldc, mi, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "C contains NaN/Inf");
+    }
+    if (!all_finite(q, n, false) || (me > 0 && !all_finite(b, me, false)) || (mi > 0 && !all_finite(d, mi, false)))
+        return fail_with(nullptr, QPS_ERR_NOT_FINITE, "q/b/d contain NaN/Inf");
+    Handle* h = new Handle(); h->n = n; h->m = me + mi;
+    int rc = guarded(nullptr, [&] { h->proxqp = make_proxqp(device, n, me, mi, dtype, P, ldp, A, lda, b, C, ldc, d, q); });
+    if (rc != QPS_OK) { delete h; return rc; }
+    *out = reinterpret_cast<qps_handle>(h);
+    return QPS_OK;
+}
+QPS_API int32_t qps_proxqp_init_kkt(qps_handle hh) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->proxqp) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a ProxQP handle");
+    return guarded(h, [&] { h->proxqp->init_kkt(); });
+}
+QPS_API int32_t qps_proxqp_set_state(qps_handle hh, const double* x, const double* y, const double* z, const double* s) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->proxqp) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a ProxQP handle");
+    if (!x || (h->proxqp->me > 0 && !y) || (h->proxqp->mi > 0 && (!z || !s))) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "NULL state vector");
+    return guarded(h, [&] { h->proxqp->set_state(x, y, z, s); });
+}
+QPS_API int32_t qps_proxqp_get_state(qps_handle hh, double* x, double* y, double* z, double* s) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->proxqp) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a ProxQP handle");
+    return guarded(h, [&] { h->proxqp->get_state(x, y, z, s); });
+}
+QPS_API int32_t qps_proxqp_solve(qps_handle hh, const qps_proxqp_params* p, qps_proxqp_report* rep) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->proxqp) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a ProxQP handle");
+    if (!p) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "params is NULL");
+    if (p->numIterations < 0 || p->numItrConv <= 0 || !(p->rho > 0) || !(p->sigma >= 0) || !(p->tau > 0))
+        return fail_with(h, QPS_ERR_BAD_ARGUMENT, "need numIterations >= 0, numItrConv > 0, rho > 0, sigma >= 0, tau > 0");
+    return guarded(h, [&] { h->proxqp->solve(*p, rep); });
+}
+
 QPS_API int32_t qps_destroy(qps_handle hh) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!h) return QPS_OK;
     delete h->impl;
     delete h->fused_batch;
+    delete h->proxqp;
     for (auto* s : h->batch) delete s;
     delete h;
     return QPS_OK;

@@ -85,6 +85,14 @@ def test_fails_loudly_without_a_gpu(qps):
     assert e.value.status == 7 and "no CPU fallback" in str(e.value)
 
 
+def test_proxqp_defaults_are_the_reference_defaults(qps):
+    """ProxQP.jl:118 keyword defaults."""
+    from quadraticprogramsolver_amd import _lib
+    p = _lib.QpsProxQpParams()
+    _lib.check(_lib.lib().qps_proxqp_default_params(C.byref(p)))
+    assert (p.numIterations, p.epsAbs, p.epsRel, p.numItrConv, p.rho, p.sigma, p.adptRho, p.tau) == (2000, 1e-7, 1e-6, 50, 1e2, 1e-2, 1, 10.0)
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under the package or include/ may reference it."""
     pkg = os.path.join(ROOT, "quadraticprogramsolver_amd")
