@@ -164,7 +164,7 @@ typedef struct {
     int32_t numIterations;   /* 2000 */
     int32_t numItrConv;      /* 50 */
     int32_t adptRho;         /* adptΡ, default 1 */
-    int32_t reserved;
+    int32_t loopVariant;     /* additive: 0 = auto (one fused pass over [A; C] per iteration), 1 = unfused (two passes) */
     double epsAbs;           /* ϵAbs 1e-7 */
     double epsRel;           /* ϵRel 1e-6 */
     double rho;              /* ρ 1e2 */

@@ -118,7 +118,7 @@ end
 # Mirrors `ProxQP(mP, vQ, mA, vB, mC, vD)` (ProxQP.jl:73-93) and `SolveQuadraticProgram!(sQpProb; ...)` (:118-173).
 # ---------------------------------------------------------------------------------------------------------------------
 struct QpsProxQpParams
-    numIterations::Int32; numItrConv::Int32; adptRho::Int32; reserved::Int32
+    numIterations::Int32; numItrConv::Int32; adptRho::Int32; loopVariant::Int32
     epsAbs::Float64; epsRel::Float64; rho::Float64; sigma::Float64; tau::Float64
 end
 mutable struct QpsProxQpReport

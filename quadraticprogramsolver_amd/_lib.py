@@ -64,7 +64,7 @@ class QpsInfo(C.Structure):
 
 
 class QpsProxQpParams(C.Structure):
-    _fields_ = [("numIterations", C.c_int32), ("numItrConv", C.c_int32), ("adptRho", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("numIterations", C.c_int32), ("numItrConv", C.c_int32), ("adptRho", C.c_int32), ("loopVariant", C.c_int32),
                 ("epsAbs", C.c_double), ("epsRel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double), ("tau", C.c_double)]
 
 

@@ -62,11 +62,17 @@ template <typename T> int apass_plan(int NP, int MP, int* rows_per_wg, int count
 template <typename T> int apass_max_np();
 // Batched form: blockIdx.y = QP; strides are MP*ld (A), NP (n-vectors), MP (m-vectors), slabs*part_ld (slabs), 16 (slots);
 // rho_arr (double per QP) overrides the scalar rho; active masks finished QPs.
-struct PassBatch { int count = 1; int slabs = 0; const double* rho_arr = nullptr; const int* active = nullptr; };
+struct PassBatch { int count = 1; int slabs = 0; const double* rho_arr = nullptr; const int* active = nullptr; int pq_me = 0; };
 template <typename T>
 void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, const T* xx, const T* x_old, T* x_new, T* z,
            T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2, int64_t part_ld, unsigned long long* slots,
            PassBatch pb = PassBatch());
+// ProxQP.jl rows over G = [A; C] (k_pass_pq.hip): v = G x, slack/dual updates (ProxQP.jl:227-249) and the slabs of
+// G'[rho b - y ; rho (d - s) - z] for the next right-hand side (:212-216) in one read of G.  Returns the slab count (0: unsupported).
+template <typename T> int apass_proxqp_slabs(int NP, int MP);
+template <typename T>
+int apass_proxqp(hipStream_t st, const T* G, int64_t ld, int NP, int MP, int me, const T* x, T* x_scratch, T* slack, T* dual,
+                 const T* g, T rho, T* part, int64_t part_ld);
 
 // ---- fused triangular sweeps (k_trsv.hip) -----------------------------------------------------------------------------
 template <typename T> bool sweep_fused_supported(int NP);

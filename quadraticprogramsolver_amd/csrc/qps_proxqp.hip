@@ -108,7 +108,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         G = dalloc<T>((int64_t)MP * NP); Aonly = dalloc<T>((int64_t)MEP * NP); P = dalloc<T>(nn); q = dalloc<T>(NP); x = dalloc<T>(NP);
         g = dalloc<T>(MP); dual = dalloc<T>(MP); slack = dalloc<T>(MP); w = dalloc<T>(MP); v = dalloc<T>(MP); de = dalloc<T>(MP); di = dalloc<T>(MP);
         tt = dalloc<T>(NP); yv = dalloc<T>(NP); xx = dalloc<T>(NP); X1 = dalloc<T>(NP); X2 = dalloc<T>(NP); X3 = dalloc<T>(NP);
-        part_tiles = gemv_cols_tiles(MP);
+        part_tiles = std::max(gemv_cols_tiles(MP), apass_proxqp_slabs<T>(NP, MP));
         part = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
         sw_part = dalloc<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
         PI = dalloc<T>(nn); KK = dalloc<T>(nn); M = dalloc<T>(nn); S = dalloc<T>(nn); tmp = dalloc<T>(nn); dinv = dalloc<T>((int64_t)(NP / 64) * 4096);
@@ -258,14 +258,26 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         double rho = p.rho; const double sigma = p.sigma;
         int converged = 0, conv_it = p.numIterations; double resP = INFINITY, resD = INFINITY, rho_rep = p.rho;
         update_decomposition(rho, sigma);                                                           // ProxQP.jl:131
+        // Fused iteration (default): one read of G per iteration -- the pass leaves the slabs of G'w for the next right-hand
+        // side, so only the first iteration, the iteration after a check and a rho change form them with the two-kernel path.
+        const bool fused = p.loopVariant != 1 && apass_proxqp_slabs<T>(NP, MP) > 0;
+        int slabs = 0;                                                                              // > 0: part holds the slabs of G'w for the current (s, y, z)
         for (int ii = 1; ii <= p.numIterations; ++ii) {                                             // :135
-            hipLaunchKernelGGL((k_pq_w<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, dual, slack, (T)rho, w);
-            const int tiles = gemv_cols_partial<T>(st, G, NP, w, nullptr, T(1), T(0), part, NP, MP, NP);   // G'w (:213,216)
-            colsum<T>(st, part, NP, tiles, x, (T)sigma, q, T(-1), tt, NP);                            // :211
+            const bool check = (ii % p.numItrConv == 0);
+            if (slabs == 0) {
+                hipLaunchKernelGGL((k_pq_w<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, dual, slack, (T)rho, w);
+                slabs = gemv_cols_partial<T>(st, G, NP, w, nullptr, T(1), T(0), part, NP, MP, NP);        // G'w (:213,216)
+            }
+            colsum<T>(st, part, NP, slabs, x, (T)sigma, q, T(-1), tt, NP);                            // :211
             sweeps(S, NP, nb, tt, x, yv);                                                           // :224 (no relaxation: x = M^{-1} r)
-            gemv_rows<T>(st, G, NP, x, v, nullptr, T(1), T(0), 0, MP, 0, NP, 0);                     // A x and C x
-            hipLaunchKernelGGL((k_pq_update<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, v, dual, slack, (T)rho);   // :227-249
-            if (ii % p.numItrConv == 0) {                                                           // :151  CheckConvergence! :252-298
+            if (fused && !check) {
+                slabs = apass_proxqp<T>(st, G, NP, NP, MP, (int)me, x, xx, slack, dual, g, (T)rho, part, NP);   // :227-249 + next :212-216
+            } else {
+                gemv_rows<T>(st, G, NP, x, v, nullptr, T(1), T(0), 0, MP, 0, NP, 0);                 // A x and C x (kept: the check reads v)
+                hipLaunchKernelGGL((k_pq_update<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, v, dual, slack, (T)rho);   // :227-249
+                slabs = 0;
+            }
+            if (check) {                                                                            // :151  CheckConvergence! :252-298
                 gemv_rows<T>(st, P, NP, x, X1, nullptr, T(1), T(0), 0, NP, 0, NP, 0);                // :261
                 hipLaunchKernelGGL((k_pq_split<T>), g1(MP), dim3(256), 0, st, (int)me, MP, dual, de, di);
                 int t2 = gemv_cols_partial<T>(st, G, NP, de, nullptr, T(1), T(0), part, NP, MP, NP);

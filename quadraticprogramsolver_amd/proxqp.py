@@ -83,12 +83,12 @@ class ProxQP:
         self.close()
 
 
-def SolveQuadraticProgramProxQP(sQpProb: ProxQP, *, numIterations=2000, ϵAbs=1e-7, ϵRel=1e-6, numItrConv=50, ρ=1e2, σ=1e-2, adptΡ=True, τ=10.0):
+def SolveQuadraticProgramProxQP(sQpProb: ProxQP, *, numIterations=2000, ϵAbs=1e-7, ϵRel=1e-6, numItrConv=50, ρ=1e2, σ=1e-2, adptΡ=True, τ=10.0, loopVariant=0):
     """``SolveQuadraticProgram!(sQpProb :: ProxQP; ...)`` (ProxQP.jl:118-173): updates sQpProb.vX/vY/vZ/vS, returns the report
     dict with the reference's keys.  Like the reference it always runs ``numIterations`` iterations."""
     p = QpsProxQpParams()
     _lib.check(_lib.lib().qps_proxqp_default_params(C.byref(p)))
-    p.numIterations, p.numItrConv, p.adptRho = int(numIterations), int(numItrConv), int(bool(adptΡ))
+    p.numIterations, p.numItrConv, p.adptRho, p.loopVariant = int(numIterations), int(numItrConv), int(bool(adptΡ)), int(loopVariant)
     p.epsAbs, p.epsRel, p.rho, p.sigma, p.tau = float(ϵAbs), float(ϵRel), float(ρ), float(σ), float(τ)
     rep = QpsProxQpReport()
     _lib.check(_lib.lib().qps_proxqp_solve(sQpProb._h, C.byref(p), C.byref(rep)), sQpProb._h)

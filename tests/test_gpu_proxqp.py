@@ -40,10 +40,12 @@ def test_kkt_initialisation_matches_reference_constructor(gpu, po, n, me, mi):
         assert rel(prob.vS, ref.vS) <= 1e-8 and np.all(prob.vZ == 0)
 
 
-@pytest.mark.parametrize("n,me,mi,feasible", [(90, 30, 70, True), (90, 60, 70, False), (64, 0, 100, True), (300, 100, 400, True)])
+@pytest.mark.parametrize("n,me,mi,feasible", [(90, 30, 70, True), (90, 60, 70, False), (64, 0, 100, True), (300, 100, 400, True), (1100, 0, 1500, True)])
 @pytest.mark.parametrize("adpt", [False, True])
-def test_iterates_and_report_match_oracle(gpu, po, n, me, mi, feasible, adpt):
-    """Same state after K iterations and the same report dict (ProxQP.jl:127,153-169), incl. rho updates and refactors."""
+@pytest.mark.parametrize("variant", [0, 1])
+def test_iterates_and_report_match_oracle(gpu, po, n, me, mi, feasible, adpt, variant):
+    """Same state after K iterations and the same report dict (ProxQP.jl:127,153-169), incl. rho updates and refactors.
+    variant 0 = one fused pass over [A; C] per iteration (default), 1 = the unfused two-pass loop."""
     P, q, A, b, C, d = make_problem(n, me, mi, 11, feasible)
     for K in (50, 200):
         ref = po.ProxQP.from_problem(P, q, A, b, C, d)
@@ -51,7 +53,7 @@ def test_iterates_and_report_match_oracle(gpu, po, n, me, mi, feasible, adpt):
         # explicit-state constructor (ProxQP.jl:36) seeded with the oracle's initial state: isolates the loop
         init = po.ProxQP.from_problem(P, q, A, b, C, d)
         with gpu.ProxQP(P, q, A, b, C, d, init.vX, init.vY, init.vZ, init.vS) as prob:
-            rg = gpu.SolveQuadraticProgramProxQP(prob, numIterations=K, ρ=200.0, σ=1e-2, adptΡ=adpt, τ=10.0)
+            rg = gpu.SolveQuadraticProgramProxQP(prob, numIterations=K, ρ=200.0, σ=1e-2, adptΡ=adpt, τ=10.0, loopVariant=variant)
             assert rel(prob.vX, ref.vX) <= 1e-8 and rel(prob.vY, ref.vY) <= 1e-7 and rel(prob.vZ, ref.vZ) <= 1e-7 and rel(prob.vS, ref.vS) <= 1e-8
             assert rg["Converged"] == rr["Converged"] and rg["Iterations"] == rr["Iterations"]
             assert abs(rg["ρ"] - rr["ρ"]) <= 1e-9 * rr["ρ"] and rg["σ"] == rr["σ"]
