@@ -61,8 +61,8 @@ typedef struct {
     int32_t numIterations;   /* 5000 */
     int32_t adptRho;         /* adptΡ, 0/1, default 0 */
     int32_t numItrConv;      /* 25 */
-    int32_t numItrPolish;    /* 10 (ignored) */
-    int32_t numItrMinres;    /* 500 (ignored) */
+    int32_t numItrPolish;    /* 10; used only when polish != 0 (the Julia loop reserves the kwarg without using it) */
+    int32_t numItrMinres;    /* 500; polishing only */
     int32_t linsys;          /* qps_linsys_kind, additive, default AUTO */
     int32_t trsvBlock;       /* additive: size of the inverted diagonal blocks of the blocked triangular sweep; a
                                 power-of-two multiple of 64, 0 = library default min(4096, n padded)                  */
@@ -73,15 +73,19 @@ typedef struct {
     double rho;              /* ρ 1 */
     double sigma;            /* σ 1e-6 */
     double alpha;            /* α 1.6 */
-    double delta;            /* δ 1e-6 (ignored) */
+    double delta;            /* δ 1e-6; polishing only */
     double fctrRho;          /* fctrΡ 5 */
-    double epsMinres;        /* ϵMinres 1e-6 (ignored) */
+    double epsMinres;        /* ϵMinres 1e-6; polishing only */
     double epsPcg;           /* CG plugins' ϵPcg 1e-6 (LinearSystemSolvers.jl:125) */
     int32_t numItrPcg;       /* CG plugins' numItrPcg 1000 */
     int32_t loopVariant;     /* additive: 0 = automatic: small problems run the whole loop in one single-workgroup launch,
                                 larger ones use the fused single pass over A per iteration when the shape allows (default);
                                 1 = unfused kernels (A read twice; the literal order of LinearSystemSolvers.jl:134-139);
                                 2 = multi-launch fused loop even for small problems */
+    int32_t polish;          /* additive: 0 = no polishing (what SolveQuadraticProgram.jl does, default); 1 = run the polishing step
+                                of SolveQuadraticProgram.m:289-325 after the loop with numItrPolish, delta, epsMinres, numItrMinres
+                                (dense handles) */
+    int32_t reserved0;
 } qps_params;
 
 /* Additive out-of-band report (the reference returns only the flag, SolveQuadraticProgram.jl:73). */
@@ -97,6 +101,10 @@ typedef struct {
     double tSetup;           /* seconds: LinSysSolInit (assembly + factorisation), device time incl. sync */
     double tLoop;            /* seconds: the iteration loop, device time incl. sync */
     double tRefactor;        /* seconds spent in changedΡ re-factorisations (part of tLoop) */
+    int32_t polishFlag;      /* minresFlag of SolveQuadraticProgram.m:311-325: -1 polishing did not run, 0 converged (x replaced),
+                                1 the last MINRES call did not converge (x kept) */
+    int32_t polishIterations;/* total MINRES iterations of the polishing step */
+    double tPolish;          /* seconds spent polishing (not part of tLoop) */
 } qps_info;
 
 /* Fill *p with the reference defaults (SolveQuadraticProgram.jl:15-17). */
@@ -123,6 +131,22 @@ int32_t qps_create_csc(int64_t n, int64_t m,
 /* SolveQuadraticProgram! (SolveQuadraticProgram.jl:14-76): x_inout is vX (warm start in, solution out, length n);
  * z and y restart at 0 (:39-40).  info may be NULL.  Blocks until the result is in x_inout. */
 int32_t qps_solve(qps_handle h, double *x_inout, const qps_params *params, qps_info *info);
+
+/* The polishing step alone (SolveQuadraticProgram.m:289-325; MATLAB only -- the Julia loop reserves its kwargs,
+ * SolveQuadraticProgram.jl:16-17): active sets from the sign of the multiplier y (length m), reduced KKT system, iterative
+ * refinement with MINRES (numItrPolish, delta, epsMinres, numItrMinres of *params).  x_inout (length n) is replaced by the
+ * polished primal only when report->flag == 0.  Dense handles. */
+typedef struct {
+    int32_t flag;              /* minresFlag: -1 did not run (numItrPolish <= 0), 0 converged, 1 not converged (x kept) */
+    int32_t refinements;       /* bodies of the refinement loop executed (<= numItrPolish) */
+    int32_t minresIterations;  /* total MINRES iterations */
+    int32_t numActiveLower;    /* numL = sum(vY < 0) */
+    int32_t numActiveUpper;    /* numU = sum(vY > 0) */
+    int32_t reserved0;
+    double relres;             /* ||r|| / ||b|| of the last MINRES call */
+    double seconds;
+} qps_polish_report;
+int32_t qps_polish(qps_handle h, double *x_inout, const double *y, const qps_params *params, qps_polish_report *report);
 
 /* Final z and y of the last qps_solve (length m each; either pointer may be NULL). Additive. */
 int32_t qps_get_dual(qps_handle h, double *z_out, double *y_out);

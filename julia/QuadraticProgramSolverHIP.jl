@@ -18,13 +18,14 @@ struct QpsParams
     linsys::Int32; trsvBlock::Int32; reuseFactor::Int32
     epsAbs::Float64; epsRel::Float64; rho::Float64; sigma::Float64; alpha::Float64; delta::Float64
     fctrRho::Float64; epsMinres::Float64; epsPcg::Float64
-    numItrPcg::Int32; loopVariant::Int32
+    numItrPcg::Int32; loopVariant::Int32; polish::Int32; reserved0::Int32
 end
 mutable struct QpsInfo
     convFlag::Int32; iterations::Int32; numRefactor::Int32; cgIterations::Int32
     rhoFinal::Float64; rhoProposed::Float64; resPrim::Float64; resDual::Float64
     tSetup::Float64; tLoop::Float64; tRefactor::Float64
-    QpsInfo() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    polishFlag::Int32; polishIterations::Int32; tPolish::Float64
+    QpsInfo() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1, 0, 0.0)
 end
 
 struct HipCholInitT end;  const HipCholInit = HipCholInitT()      # dense reduced-form Cholesky on the device
@@ -64,11 +65,12 @@ end
 
 function _solve!(vX::Vector{Float64}, mP, vQ, mA, vL, vU, densePath::Bool;
     numIterations = 5000, ϵAbs = 1e-6, ϵRel = 1e-6, ρ = 1, σ = 1e-6, α = 1.6, δ = 1e-6, adptΡ::Bool = false,
-    fctrΡ = 5, numItrConv = 25, numItrPolish = 10, ϵMinres = 1e-6, numItrMinres = 500, info = nothing)
+    fctrΡ = 5, numItrConv = 25, numItrPolish = 10, ϵMinres = 1e-6, numItrMinres = 500, info = nothing,
+    polish::Bool = false)   # polish = true: the polishing step of SolveQuadraticProgram.m:289-325 (the Julia loop reserves its kwargs unused)
     h = _create(mP, Vector{Float64}(vQ), mA, Vector{Float64}(vL), Vector{Float64}(vU); densePath = densePath)
     try
         prm = QpsParams(numIterations, adptΡ, numItrConv, numItrPolish, numItrMinres, densePath ? 1 : 2, 0, 0,
-                        ϵAbs, ϵRel, ρ, σ, α, δ, fctrΡ, ϵMinres, 1e-6, 1000, 0)
+                        ϵAbs, ϵRel, ρ, σ, α, δ, fctrΡ, ϵMinres, 1e-6, 1000, 0, polish, 0)
         inf = QpsInfo()
         GC.@preserve vX _check(ccall((:qps_solve, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{QpsParams}, Ref{QpsInfo}),
                                      h, vX, Ref(prm), inf), h)

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
     "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
     "qps_proxqp_default_params", "qps_proxqp_create_dense", "qps_proxqp_init_kkt", "qps_proxqp_set_state", "qps_proxqp_get_state",
-    "qps_proxqp_solve",
+    "qps_proxqp_solve", "qps_polish",
 ]
 
 QPS_OK = 0
@@ -50,17 +50,26 @@ class QpsParams(C.Structure):
                 ("trsvBlock", C.c_int32), ("reuseFactor", C.c_int32),
                 ("epsAbs", C.c_double), ("epsRel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
                 ("alpha", C.c_double), ("delta", C.c_double), ("fctrRho", C.c_double), ("epsMinres", C.c_double),
-                ("epsPcg", C.c_double), ("numItrPcg", C.c_int32), ("loopVariant", C.c_int32)]
+                ("epsPcg", C.c_double), ("numItrPcg", C.c_int32), ("loopVariant", C.c_int32),
+                ("polish", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class QpsInfo(C.Structure):
     _fields_ = [("convFlag", C.c_int32), ("iterations", C.c_int32), ("numRefactor", C.c_int32),
                 ("cgIterations", C.c_int32), ("rhoFinal", C.c_double), ("rhoProposed", C.c_double),
                 ("resPrim", C.c_double), ("resDual", C.c_double), ("tSetup", C.c_double), ("tLoop", C.c_double),
-                ("tRefactor", C.c_double)]
+                ("tRefactor", C.c_double), ("polishFlag", C.c_int32), ("polishIterations", C.c_int32), ("tPolish", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class QpsPolishReport(C.Structure):
+    _fields_ = [("flag", C.c_int32), ("refinements", C.c_int32), ("minresIterations", C.c_int32), ("numActiveLower", C.c_int32),
+                ("numActiveUpper", C.c_int32), ("reserved0", C.c_int32), ("relres", C.c_double), ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved0"}
 
 
 class QpsProxQpParams(C.Structure):
@@ -112,6 +121,7 @@ def lib() -> C.CDLL:
     L.qps_create_dense.argtypes = [i64, i64, dp, i64, dp, i64, dp, dp, dp, i32, i32, C.POINTER(hp)]
     L.qps_create_csc.argtypes = [i64, i64, ip, ip, dp, ip, ip, dp, dp, dp, dp, i32, i32, i32, i32, C.POINTER(hp)]
     L.qps_solve.argtypes = [hp, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo)]
+    L.qps_polish.argtypes = [hp, dp, dp, C.POINTER(QpsParams), C.POINTER(QpsPolishReport)]
     L.qps_get_dual.argtypes = [hp, dp, dp]
     L.qps_linsys_init.argtypes = [hp, dbl, dbl, i32, i32]
     L.qps_linsys_solve.argtypes = [hp, dp, dp, dp, dbl, dbl, i32, dp, dp]

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
         T* xp_ = reinterpret_cast<T*>(&xv[k]);
         if (c < NP) {
             xv[k] = *reinterpret_cast<const V*>(xx + c);
-            if (CHECK || g == 0) {
+            if (CHECK || (g == 0 && MODE != 2)) {
                 const V xo = *reinterpret_cast<const V*>(x_old + c);
                 const T* xop = reinterpret_cast<const T*>(&xo);
                 V xnv;
@@ -173,6 +173,12 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
                 zn = t > hi ? hi : (t < lo ? lo : t);                               //     clamp(., vL, vU)
                 yn = yo + rho * (alpha * zt + alpha1 * zo - zn);                    // :61
                 wsh[tid] = rho * zn - yn;                                           // LinearSystemSolvers.jl:134
+            } else if (MODE == 2) {
+                // masked KKT product of the polishing step (SolveQuadraticProgram.m:304-305): l-array = 0/1 mask of the active
+                // rows, y-array = multiplier block of the input (read only), alpha = delta; out = mask (A v_x) - delta mask v_lambda
+                zn = lo * zt - alpha * (lo * yo);
+                yn = yo;
+                wsh[tid] = lo * yo;
             } else {
                 // ProxQP.jl rows over G = [A; C]: z-array = slack s, y-array = dual (y | z), l-array = bound (b | d), zt = (G x)_row
                 const T gb = lo, vr = zt;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
                 }
             }
             z[row + tid] = zn;
-            y[row + tid] = yn;
+            if (MODE != 2) y[row + tid] = yn;
             if (CHECK) {
                 ysh[tid] = yn;
                 m_res = umax(m_res, absbits((double)(ax - zn)));                    // :85

@@ -398,6 +398,7 @@ template <typename T> struct SparseSolver : SolverBase {
             info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
             info->numRefactor = nref; info->cgIterations = (int)cg_total; info->rhoFinal = rho; info->rhoProposed = rhorho;
             info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = 0;
+            info->polishFlag = -1; info->polishIterations = 0; info->tPolish = 0;
         }
     }
     void get_dual(double* zh, double* yh) override {

@@ -5,6 +5,7 @@
 // There is NO CPU fallback: without a HIP device every entry point fails with QPS_ERR_NO_DEVICE.
 #include "qps_internal.h"
 #include "qps_kernels.h"
+#include "qps_polish.h"
 #include "qps_proxqp.h"
 
 using namespace qps;
@@ -34,7 +35,7 @@ template <typename T> struct DenseSolver : SolverBase {
     int pass_slabs = 0, pass_rpw = 0;   // fused-pass plan (0 slabs: shape not supported, unfused loop only)
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
-    int nb = 2048; int part_tiles = 0;
+    int nb = 2048; int part_tiles = 0; int num_factorizations = 0;
     int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk, cat_sweep, cat_xsum;
 
     DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
@@ -136,9 +137,10 @@ template <typename T> struct DenseSolver : SolverBase {
         int f = 0;
         HIPC(hipMemcpyAsync(&f, fail, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
+        ++num_factorizations;
         if (f != 0) {
             factor_valid = false;
-            char b[256]; snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A broke down: non-positive pivot at column %d (rho=%g, sigma=%g)", f, rho, sigma);
+            char b[256]; snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A broke down: non-positive pivot at column %d (rho=%g, sigma=%g; factorisation #%d of this handle)", f, rho, sigma, num_factorizations);
             throw QpsError(QPS_ERR_FACTORIZATION, b);
         }
         factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb;
@@ -230,11 +232,14 @@ template <typename T> struct DenseSolver : SolverBase {
             }
             ii = it;
             const double t2s = now_s();
+            PolishReport prs;
+            if (p.polish) polish_dense<T>(st, n, m, NP, MP, P, A, q, l, u, y, x, part, p, &prs);   // SolveQuadraticProgram.m:289-325
             download_vec(x, xh, n);
             if (info) {
                 info->convFlag = convFlag; info->iterations = ii; info->numRefactor = nref; info->cgIterations = 0;
                 info->rhoFinal = rho; info->rhoProposed = rhorho; info->resPrim = resP; info->resDual = resD;
                 info->tSetup = t1 - t0; info->tLoop = t2s - t1; info->tRefactor = tref;
+                info->polishFlag = prs.flag; info->polishIterations = prs.minresIterations; info->tPolish = prs.seconds;
             }
             return;
         }
@@ -305,11 +310,25 @@ template <typename T> struct DenseSolver : SolverBase {
         HIPC(hipStreamSynchronize(st));
         prof.harvest();
         const double t2 = now_s();
+        PolishReport pr;
+        if (p.polish) polish_dense<T>(st, n, m, NP, MP, P, A, q, l, u, y, x, part, p, &pr);        // SolveQuadraticProgram.m:289-325
         download_vec(x, xh, n);
         if (info) {
             info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
             info->numRefactor = nref; info->cgIterations = 0; info->rhoFinal = rho; info->rhoProposed = rhorho;
             info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = tref;
+            info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
+        }
+    }
+    void polish(double* xh, const double* yh, const qps_params& p, qps_polish_report* rep) override {
+        HIPC(hipSetDevice(device));
+        upload_vec(xh, x, n); upload_vec(yh, y, m);
+        PolishReport pr;
+        polish_dense<T>(st, n, m, NP, MP, P, A, q, l, u, y, x, part, p, &pr);
+        download_vec(x, xh, n);
+        if (rep) {
+            rep->flag = pr.flag; rep->refinements = pr.refinements; rep->minresIterations = pr.minresIterations;
+            rep->numActiveLower = pr.numLower; rep->numActiveUpper = pr.numUpper; rep->reserved0 = 0; rep->relres = pr.relres; rep->seconds = pr.seconds;
         }
     }
     void get_dual(double* zh, double* yh) override {
@@ -558,6 +577,11 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             if (active[b]) HIPC(hipMemcpyAsync(xres + (int64_t)b * NP, x + (int64_t)b * NP, sizeof(T) * NP, hipMemcpyDeviceToDevice, st));
         HIPC(hipStreamSynchronize(st));
         const double t2 = now_s();
+        std::vector<PolishReport> pol(count);
+        if (p.polish)                                                                               // SolveQuadraticProgram.m:289-325, one QP after the other
+            for (int b = 0; b < count; ++b)
+                polish_dense<T>(st, n, m, NP, MP, P + (int64_t)b * NP * NP, A + (int64_t)b * MP * NP, q + (int64_t)b * NP, l + (int64_t)b * MP,
+                                u + (int64_t)b * MP, y + (int64_t)b * MP, xres + (int64_t)b * NP, part, p, &pol[b]);
         for (int b = 0; b < count; ++b) {
             convert_back<T>(st, xres + (int64_t)b * NP, stage, n);
             HIPC(hipMemcpyAsync(xh + (int64_t)b * n, stage, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -567,6 +591,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 in.convFlag = conv[b]; in.iterations = iters[b]; in.numRefactor = nref[b]; in.cgIterations = 0;
                 in.rhoFinal = rho[b]; in.rhoProposed = rhorho[b]; in.resPrim = resP[b]; in.resDual = resD[b];
                 in.tSetup = t1 - t0; in.tLoop = t2 - t1; in.tRefactor = tref[b];   // wall time of the whole batch
+                in.polishFlag = pol[b].flag; in.polishIterations = pol[b].minresIterations; in.tPolish = pol[b].seconds;
             }
         }
     }
@@ -731,6 +756,16 @@ QPS_API int32_t qps_solve(qps_handle hh, double* x, const qps_params* p, qps_inf
     if (rc != QPS_OK) return rc;
     if (!all_finite(x, h->n, false)) return fail_with(h, QPS_ERR_NOT_FINITE, "x_inout (warm start) contains NaN/Inf");
     return guarded(h, [&] { h->impl->solve(x, *p, info); });
+}
+
+QPS_API int32_t qps_polish(qps_handle hh, double* x, const double* y, const qps_params* p, qps_polish_report* rep) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (!x || (h->m > 0 && !y)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "NULL vector");
+    int rc = validate_params(h, p);
+    if (rc != QPS_OK) return rc;
+    if (!all_finite(x, h->n, false) || !all_finite(y, h->m, false)) return fail_with(h, QPS_ERR_NOT_FINITE, "x or y contains NaN/Inf");
+    return guarded(h, [&] { h->impl->polish(x, y, *p, rep); });
 }
 
 QPS_API int32_t qps_get_dual(qps_handle hh, double* z, double* y) {

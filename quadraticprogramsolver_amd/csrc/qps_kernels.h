@@ -70,6 +70,10 @@ void apass(hipStream_t st, bool check, const T* A, int64_t ld, int NP, int MP, c
 // ProxQP.jl rows over G = [A; C] (k_pass_pq.hip): v = G x, slack/dual updates (ProxQP.jl:227-249) and the slabs of
 // G'[rho b - y ; rho (d - s) - z] for the next right-hand side (:212-216) in one read of G.  Returns the slab count (0: unsupported).
 template <typename T> int apass_proxqp_slabs(int NP, int MP);
+// polishing (SolveQuadraticProgram.m:304-305): out_lam = mask (A vx) - delta mask vlam, slabs of A'(mask vlam); 0: unsupported shape
+template <typename T>
+int apass_kkt(hipStream_t st, const T* A, int64_t ld, int NP, int MP, const T* vx, const T* vlam, const T* mask, T delta, T* out_lam,
+              T* part, int64_t part_ld);
 template <typename T>
 int apass_proxqp(hipStream_t st, const T* G, int64_t ld, int NP, int MP, int me, const T* x, T* x_scratch, T* slack, T* dual,
                  const T* g, T rho, T* part, int64_t part_ld);

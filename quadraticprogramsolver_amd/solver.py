@@ -105,8 +105,9 @@ class QuadraticProgram:
     # -- SolveQuadraticProgram! -----------------------------------------------------------------------------------
     def solve(self, vX, *, numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=False, fctrΡ=5,
               numItrConv=25, numItrPolish=10, ϵMinres=1e-6, numItrMinres=500, ϵPcg=1e-6, numItrPcg=1000,
-              trsvBlock=0, reuseFactor=False, loopVariant=0, info=None):
-        """Mutates ``vX`` (warm start in, solution out) and returns the ConvergenceFlag."""
+              trsvBlock=0, reuseFactor=False, loopVariant=0, polish=False, info=None):
+        """Mutates ``vX`` (warm start in, solution out) and returns the ConvergenceFlag.  ``polish=True`` appends the
+        polishing step of SolveQuadraticProgram.m:289-325 (off by default: the Julia loop reserves its kwargs unused)."""
         if not isinstance(vX, np.ndarray) or vX.dtype != np.float64 or not vX.flags.c_contiguous or vX.shape != (self.n,):
             raise ValueError("vX must be a contiguous float64 vector of length numElements (it is updated in place)")
         p = _lib.default_params()
@@ -116,12 +117,26 @@ class QuadraticProgram:
         p.numItrPolish, p.epsMinres, p.numItrMinres = int(numItrPolish), float(ϵMinres), int(numItrMinres)
         p.epsPcg, p.numItrPcg = float(ϵPcg), int(numItrPcg)
         p.linsys, p.trsvBlock, p.reuseFactor = self.linsys, int(trsvBlock), int(bool(reuseFactor))
-        p.loopVariant = int(loopVariant)
+        p.loopVariant, p.polish = int(loopVariant), int(bool(polish))
         inf = QpsInfo()
         _lib.check(_lib.lib().qps_solve(self._h, _dp(vX), C.byref(p), C.byref(inf)), self._h)
         if info is not None:
             info.update(inf.as_dict())
         return ConvergenceFlag(inf.convFlag)
+
+    def polish(self, vX, vY, *, numItrPolish=10, δ=1e-6, ϵMinres=1e-6, numItrMinres=500):
+        """The polishing step alone (SolveQuadraticProgram.m:289-325) from a primal ``vX`` (updated in place when MINRES
+        converged) and a multiplier ``vY``.  Returns the report dict (flag 0 = polished, 1 = kept, -1 = did not run)."""
+        if not isinstance(vX, np.ndarray) or vX.dtype != np.float64 or not vX.flags.c_contiguous or vX.shape != (self.n,):
+            raise ValueError("vX must be a contiguous float64 vector of length numElements (it is updated in place)")
+        y = np.ascontiguousarray(vY, dtype=np.float64)
+        if y.shape != (self.m,):
+            raise ValueError("vY must have length numConstraints")
+        p = _lib.default_params()
+        p.numItrPolish, p.delta, p.epsMinres, p.numItrMinres, p.polish = int(numItrPolish), float(δ), float(ϵMinres), int(numItrMinres), 1
+        rep = _lib.QpsPolishReport()
+        _lib.check(_lib.lib().qps_polish(self._h, _dp(vX), _dp(y if self.m else np.zeros(1)), C.byref(p), C.byref(rep)), self._h)
+        return rep.as_dict()
 
     def dual(self):
         """(z, y) of the last solve (additive: the reference discards them)."""
@@ -198,7 +213,7 @@ class QuadraticProgramBatch:
         self._h = h
 
     def solve(self, mX=None, *, numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, adptΡ=False, fctrΡ=5, numItrConv=25,
-              trsvBlock=0, reuseFactor=False):
+              trsvBlock=0, reuseFactor=False, polish=False, numItrPolish=10, δ=1e-6, ϵMinres=1e-6, numItrMinres=500):
         """Returns (mX [count x n], list of ConvergenceFlag, list of info dicts).  ``mX`` (optional) holds the warm starts."""
         X = np.zeros((self.count, self.n)) if mX is None else np.ascontiguousarray(mX, dtype=np.float64).copy()
         p = _lib.default_params()
@@ -206,6 +221,7 @@ class QuadraticProgramBatch:
         p.rho, p.sigma, p.alpha = float(ρ), float(σ), float(α)
         p.adptRho, p.fctrRho, p.numItrConv = int(bool(adptΡ)), float(fctrΡ), int(numItrConv)
         p.trsvBlock, p.reuseFactor = int(trsvBlock), int(bool(reuseFactor))
+        p.polish, p.numItrPolish, p.delta, p.epsMinres, p.numItrMinres = int(bool(polish)), int(numItrPolish), float(δ), float(ϵMinres), int(numItrMinres)
         infos = (QpsInfo * self.count)()
         _lib.check(_lib.lib().qps_solve_batch(self._h, _dp(X), C.byref(p), infos), self._h)
         return X, [ConvergenceFlag(i.convFlag) for i in infos], [i.as_dict() for i in infos]
@@ -256,10 +272,11 @@ HipCholF32Init, HipCholF32 = _make_pair("cholesky", "f32")
 def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholInit, LinSysSol=HipChol, *,
                                  numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=False,
                                  fctrΡ=5, numItrConv=25, numItrPolish=10, ϵMinres=1e-6, numItrMinres=500, info=None,
-                                 device=0, trsvBlock=0, loopVariant=0):
+                                 device=0, trsvBlock=0, loopVariant=0, polish=False):
     """``SolveQuadraticProgram!`` (SolveQuadraticProgram.jl:14-76): mutates ``vX``, returns the ConvergenceFlag.
 
-    ``δ, numItrPolish, ϵMinres, numItrMinres`` are accepted and ignored, as in the reference (:16-17, no polish).
+    ``δ, numItrPolish, ϵMinres, numItrMinres`` are accepted and, as in the reference (:16-17, no polish), unused unless
+    ``polish=True`` asks for the polishing step of the MATLAB implementation (SolveQuadraticProgram.m:289-325).
     ``info`` (optional dict) receives iterations, final ρ, residuals, timings -- additive."""
     linsys = getattr(LinSysSolInit, "_qps_linsys", None)
     if linsys is None or getattr(LinSysSol, "_qps_linsys", None) != linsys:
@@ -268,7 +285,7 @@ def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholIn
     with QuadraticProgram(mP, vQ, mA, vL, vU, linsys=linsys, dtype=LinSysSolInit._qps_dtype, device=device) as prob:
         return prob.solve(vX, numIterations=numIterations, ϵAbs=ϵAbs, ϵRel=ϵRel, ρ=ρ, σ=σ, α=α, δ=δ, adptΡ=adptΡ,
                           fctrΡ=fctrΡ, numItrConv=numItrConv, numItrPolish=numItrPolish, ϵMinres=ϵMinres,
-                          numItrMinres=numItrMinres, trsvBlock=trsvBlock, loopVariant=loopVariant, info=info)
+                          numItrMinres=numItrMinres, trsvBlock=trsvBlock, loopVariant=loopVariant, polish=polish, info=info)
 
 
 SolveQuadraticProgram_b = SolveQuadraticProgramInplace

@@ -1,0 +1,138 @@
+"""GPU parity of the polishing step (SolveQuadraticProgram.m:289-325) against oracle/polish_oracle_np.py.
+
+The active sets come from the SIGN of the multiplier (:293-294), and the multiplier of an inactive row is rounding noise
+(±1e-18), so two correct ADMM implementations may pick different sets.  The parity tests therefore hand the SAME (x, y) to
+the device (`qps_polish`) and to the restatement; the chained form (`qps_params.polish`) is tested for consistency with
+`qps_polish` on the device's own (x, y) and for the reference's flag semantics."""
+import numpy as np
+import pytest
+
+from quadraticprogramsolver_amd.generator import GenerateDenseBenchmarkQP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pol():
+    from oracle import polish_oracle_np
+    return polish_oracle_np
+
+
+def problem(n, m, stream):
+    return tuple(np.asarray(a) for a in GenerateDenseBenchmarkQP(n, m, feasible=True, stream=stream))
+
+
+def admm_state(np_oracle, P, q, A, l, u, eps=1e-4):
+    x = np.zeros(P.shape[0]); info = {}
+    np_oracle.SolveQuadraticProgramRefLoop(x, P, q, A, l, u, np_oracle.RedCholInit, np_oracle.RedChol, numIterations=4000, εAbs=eps, εRel=eps,
+                                           ρ=0.1, adptΡ=True, info=info)
+    return x, info["y"]
+
+
+@pytest.mark.parametrize("n,m,stream", [(40, 80, 1), (64, 128, 2), (200, 150, 5), (1100, 600, 4)])
+@pytest.mark.parametrize("clean", [True, False])
+def test_polish_matches_restatement_on_the_same_state(gpu, np_oracle, pol, n, m, stream, clean):
+    """Same (x, y) in, same polished x / flag / active-set sizes out.  clean=True drops the noise of y on inactive rows (the
+    case the reference's comment :290-291 describes); clean=False is the literal sign test on the raw multiplier."""
+    P, q, A, l, u = problem(n, m, stream)
+    x, y = admm_state(np_oracle, P, q, A, l, u)
+    if clean:
+        y = np.where(np.abs(y) > 1e-7, y, 0.0)
+    tol = 1e-9 if clean else 1e-6
+    xr, fr, ir = pol.Polish(P, q, A, l, u, x, y, 10, 1e-6, tol, 4000)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        xg = x.copy()
+        rep = prob.polish(xg, y, numItrPolish=10, δ=1e-6, ϵMinres=tol, numItrMinres=4000)
+    assert rep["numActiveLower"] == ir["numActiveLower"] and rep["numActiveUpper"] == ir["numActiveUpper"]
+    assert rep["flag"] == fr
+    if fr == 0:
+        if clean:      # well-posed reduced KKT system: both reach its solution
+            assert np.abs(xg - xr).max() <= 1e-7 * max(1.0, np.abs(xr).max())
+            assert np.abs(xg - x).max() > 0
+        assert rep["refinements"] == ir["refinements"]
+    else:
+        assert np.array_equal(xg, x)                     # x kept when MINRES did not converge (:322-325)
+
+
+def test_polish_reaches_the_kkt_point_of_the_active_set(gpu, np_oracle):
+    n, m = 200, 150
+    P, q, A, l, u = problem(n, m, 5)
+    x, y = admm_state(np_oracle, P, q, A, l, u)
+    y = np.where(np.abs(y) > 1e-7, y, 0.0)
+    L, U = y < 0, y > 0
+    Aa = np.vstack([A[L], A[U]]); g = np.concatenate([-q, l[L], u[U]])
+    t = np.linalg.solve(np.block([[P, Aa.T], [Aa, np.zeros((Aa.shape[0],) * 2)]]), g)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        xg = x.copy()
+        rep = prob.polish(xg, y, ϵMinres=1e-10, numItrMinres=4000)
+    assert rep["flag"] == 0 and rep["relres"] <= 1e-10
+    assert np.abs(xg - t[:n]).max() <= 1e-9 and np.abs(x - t[:n]).max() > 1e-6      # the 1e-4 ADMM iterate was 3e-6 away
+    assert np.abs(A[L] @ xg - l[L]).max() <= 1e-6 and np.abs(A[U] @ xg - u[U]).max() <= 1e-6   # active rows sit on their bounds
+
+
+@pytest.mark.parametrize("n,m,variant", [(48, 96, 0), (48, 96, 2), (300, 500, 0)])
+def test_chained_polish_equals_solve_then_polish(gpu, n, m, variant):
+    """qps_params.polish = 1 is the loop followed by qps_polish on the loop's own (x, y); polish = 0 (default) is the Julia behaviour."""
+    P, q, A, l, u = problem(n, m, 6)
+    kw = dict(numIterations=2000, ϵAbs=1e-4, ϵRel=1e-4, ρ=0.1, adptΡ=True, loopVariant=variant)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        x0 = np.zeros(n); i0 = {}
+        prob.solve(x0, info=i0, **kw)
+        _, y = prob.dual()
+        assert i0["polishFlag"] == -1 and i0["polishIterations"] == 0
+        x1 = np.zeros(n); i1 = {}
+        f1 = prob.solve(x1, info=i1, polish=True, **kw)
+        xs = x0.copy()
+        rep = prob.polish(xs, y[:m])
+    assert i1["polishFlag"] == rep["flag"] and i1["polishIterations"] == rep["minresIterations"] and i1["iterations"] == i0["iterations"]
+    assert np.array_equal(x1, xs)
+    assert int(f1) in (1, 2, 3)
+
+
+def test_polish_flag_semantics_and_errors(gpu, np_oracle):
+    P, q, A, l, u = problem(40, 80, 1)
+    x, y = admm_state(np_oracle, P, q, A, l, u)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        xg = x.copy()
+        rep = prob.polish(xg, y, numItrPolish=0)
+        assert rep["flag"] == -1 and np.array_equal(xg, x)                     # :292,311
+        rep = prob.polish(xg, np.where(np.abs(y) > 1e-7, y, 0.0), numItrMinres=2)
+        assert rep["flag"] == 1 and rep["refinements"] == 1 and np.array_equal(xg, x)   # :316-325
+        with pytest.raises(ValueError):
+            prob.polish(xg, y[:-1])
+        bad = y.copy(); bad[0] = np.nan
+        with pytest.raises(gpu.QpsError) as e:
+            prob.polish(xg, bad)
+        assert e.value.status == 3
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:               # CSR/CG handles: not implemented, said loudly
+        with pytest.raises(gpu.QpsError) as e:
+            prob.polish(x.copy(), y)
+        assert e.value.status == 8
+
+
+def test_polish_without_constraints_is_the_unconstrained_minimiser(gpu):
+    n = 96
+    P, q, _, _, _ = problem(n, 8, 7)
+    A = np.zeros((0, n)); l = np.zeros(0); u = np.zeros(0)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        x = np.zeros(n)
+        rep = prob.polish(x, np.zeros(0), ϵMinres=1e-10, numItrMinres=2000)
+    assert rep["flag"] == 0 and rep["numActiveLower"] == 0 and rep["numActiveUpper"] == 0
+    assert np.abs(x - np.linalg.solve(P, -q)).max() <= 1e-6 * max(1.0, np.abs(x).max())
+
+
+def test_batch_polish_equals_single_problem_polish(gpu):
+    n, m, count = 64, 128, 3
+    probs = [problem(n, m, 10 + b) for b in range(count)]
+    kw = dict(numIterations=1500, ϵAbs=1e-4, ϵRel=1e-4, ρ=0.1, adptΡ=True)
+    singles = []
+    for (P, q, A, l, u) in probs:
+        with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+            x = np.zeros(n); info = {}
+            prob.solve(x, info=info, polish=True, loopVariant=2, **kw)
+            singles.append((x, info))
+    with gpu.QuadraticProgramBatch(probs) as batch:
+        X, flags, infos = batch.solve(polish=True, **kw)
+    for b in range(count):
+        assert infos[b]["polishFlag"] == singles[b][1]["polishFlag"]
+        assert np.abs(X[b] - singles[b][0]).max() <= 1e-6 * max(1.0, np.abs(singles[b][0]).max())
