@@ -92,6 +92,165 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ rb,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Column-blocked SpMV with the block of x resident in LDS.
+// The CSR-stream kernel above gathers x[col] through L1/L2: at 8 B per gather and 128-B lines the gathers of a 5 M-nnz
+// matrix move ~640 MB between L2 and L1 -- ten times the 60 MB of (col, val) that HBM has to deliver -- and bound the
+// kernel at ~2 TB/s.  Here the columns are cut into blocks of CB = 56 KiB / sizeof(T) entries; block b of the matrix is its
+// own CSR (16-bit local column indices: 10 instead of 12 bytes per non-zero) and a workgroup of block b first copies
+// x[b*CB .. (b+1)*CB) into LDS with full-line loads, then streams its tasks (consecutive rows holding <= BCHUNK non-zeros
+// of the block) with unit-stride loads and gathers from LDS.  Row sums per block go to partial[b][row]; k_spmv_combine
+// adds the blocks in fixed order and applies the epilogue (scale, two axpys, optional dot partials).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int BCHUNK = 2048;          // non-zeros per task (512 threads x 4)
+constexpr int BTHREADS = 512;
+template <typename T> struct BlkOf { static constexpr int CB = (int)(57344 / sizeof(T)); };   // 56 KiB of x + 16 KiB of products: two workgroups per CU
+
+constexpr int BROWS = 1024;           // rows per task at most (their row pointers are staged in LDS)
+constexpr int BMAXT = 64;             // tasks per workgroup at most (their descriptors are staged in LDS)
+// Optional fusion of the CG direction update into the x-block load of the operator's first product:  u_new = r + beta u_old,
+// beta from the ||r||^2 partials of the previous iteration; block (0,0) publishes the scalars (what k_cg_next_u does).
+// u_new goes to a second buffer (other workgroups of the same column block still read u_old).
+template <typename T> struct CgFuse {
+    const T* r = nullptr; const T* uold = nullptr; T* unew = nullptr; const double* part_rr = nullptr; int nparts = 0;
+    const CgState* cur = nullptr; CgState* nxt = nullptr; int first = 0;
+};
+// task descriptor: rows [x, y) of the block, non-zeros [z, w) of the blocked arrays
+template <typename T, int LPR>        // LPR lanes add up one row segment (4 when a row holds <= ~8 non-zeros per block)
+__global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, const int* __restrict__ task_ptr, const int4* __restrict__ tasks, int per,
+                                                       const int* __restrict__ rp, const unsigned short* __restrict__ ci, const T* __restrict__ va,
+                                                       const T* __restrict__ xin, T* __restrict__ partial, const CgState* __restrict__ st, CgFuse<T> fu) {
+    if (st && st->done) return;
+    constexpr int CB = BlkOf<T>::CB, XPT = CB / BTHREADS;
+    __shared__ T xs[CB];
+    __shared__ T prod[BCHUNK];
+    __shared__ int rps[BROWS + 2];
+    __shared__ int4 meta[BMAXT];
+    __shared__ double sh[BTHREADS / 64];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    T beta = T(0);
+    if (fu.r) {
+        if (fu.cur->done) { if (blockIdx.x == 0 && b == 0 && tid == 0) *fu.nxt = *fu.cur; return; }
+        double res2 = fu.cur->res2, prev2 = fu.cur->prev2; int iters = fu.cur->iters, done = 0;
+        if (!fu.first) {
+            double d = 0.0;
+            for (int i = tid; i < fu.nparts; i += BTHREADS) d += fu.part_rr[i];            // same order in every workgroup
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if ((tid & 63) == 0) sh[tid >> 6] = d;
+            __syncthreads();
+            d = 0.0;
+            for (int w = 0; w < BTHREADS / 64; ++w) d += sh[w];
+            __syncthreads();
+            prev2 = res2; res2 = d; iters += 1;
+            if (sqrt(d) <= fu.cur->tol || iters >= fu.cur->maxiter) done = 1;
+        }
+        if (blockIdx.x == 0 && b == 0 && tid == 0) { CgState s_ = *fu.cur; s_.res2 = res2; s_.prev2 = prev2; s_.iters = iters; s_.done = done; *fu.nxt = s_; }
+        if (done) return;
+        beta = (T)(res2 / prev2);
+    }
+    // this workgroup's tasks: a contiguous run [ts, te) of block b, so their descriptors come with one coalesced load and
+    // no data load ever waits on a chain of dependent loads
+    const int ts = task_ptr[b] + blockIdx.x * per, te = min(task_ptr[b + 1], ts + per), nt = te - ts;
+    if (nt <= 0) return;
+    int4 mt = make_int4(0, 0, 0, 0);
+    if (tid < nt) mt = tasks[ts + tid];
+    const int c0 = b * CB, cw = min(CB, ncols - c0);
+    T xr[XPT];                                                   // x block: all loads of a thread in flight together
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) { const int c = tid + BTHREADS * j; xr[j] = (c < cw) ? xin[c0 + c] : T(0); }
+    if (fu.r) {
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) {
+            const int c = tid + BTHREADS * j;
+            if (c < cw) { xr[j] = xr[j] + beta * fu.uold[c0 + c]; if (blockIdx.x == 0) fu.unew[c0 + c] = xr[j]; }   // xin = r
+        }
+    }
+    if (tid < nt) meta[tid] = mt;
+    __syncthreads();
+    const int* rpb = rp + (int64_t)b * (nrows + 1);
+    T* pout = partial + (int64_t)b * nrows;
+    // software pipeline, two tasks deep: (col, val) slices and row pointers of the next two tasks are in flight while one is reduced
+    struct Regs { int c[4]; T v[4]; int r[2]; int r0, r1, base, end; };
+    Regs RA, RB;
+    auto fetch = [&](Regs& R, int i) {
+        const int4 m = meta[i];
+        R.r0 = m.x; R.r1 = m.y; R.base = m.z; R.end = m.w;
+        if (!(R.r1 - R.r0 == 1 && R.end - R.base > BCHUNK)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int k = R.base + tid + BTHREADS * j; R.c[j] = (k < R.end) ? (int)ci[k] : -1; R.v[j] = (k < R.end) ? va[k] : T(0); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const int r = R.r0 + tid + BTHREADS * j; R.r[j] = (r <= R.r1) ? rpb[r] : 0; }
+        }
+    };
+    auto process = [&](Regs& R, int inext) {
+        const int r0 = R.r0, r1 = R.r1, base = R.base, end = R.end;
+        if (r1 - r0 == 1 && end - base > BCHUNK) {              // one long row of this block: strided walk + block reduction
+            if (inext < nt) fetch(R, inext);
+            T s = T(0);
+            for (int k = base + tid; k < end; k += BTHREADS) s += va[k] * xs[ci[k]];
+            double d = (double)s;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if ((tid & 63) == 0) sh[tid >> 6] = d;
+            __syncthreads();
+            if (tid == 0) { double tot = 0.0; for (int w = 0; w < BTHREADS / 64; ++w) tot += sh[w]; pout[r0] = (T)tot; }
+            __syncthreads();
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prod[tid + BTHREADS * j] = (R.c[j] >= 0) ? R.v[j] * xs[R.c[j]] : T(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int i = tid + BTHREADS * j; if (i <= r1 - r0) rps[i] = R.r[j] - base; }
+        if (inext < nt) fetch(R, inext);                        // this register set is free again
+        __syncthreads();
+        const int lane = tid & (LPR - 1);
+        for (int i = tid / LPR; i < r1 - r0; i += BTHREADS / LPR) {
+            const int s0 = rps[i], s1 = rps[i + 1];
+            T s = T(0);
+            for (int k = s0 + lane; k < s1; k += LPR) s += prod[k];
+            if (LPR == 8) s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+            if (lane == 0) pout[r0 + i] = s;
+        }
+        __syncthreads();
+    };
+    fetch(RA, 0);
+    if (nt > 1) fetch(RB, 1);
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) xs[tid + BTHREADS * j] = xr[j];
+    __syncthreads();                                            // xs complete
+    for (int i = 0; i < nt; i += 2) {
+        process(RA, i + 2);
+        if (i + 1 < nt) process(RB, i + 3);
+    }
+}
+// out[row] = a0 * sum_b p0[b][row] + a1 * sum_b p1[b][row] + b0 v0[row] + b1 v1[row]; optional partials of dot(dotv, out)
+template <typename T>
+__global__ __launch_bounds__(256) void k_spmv_combine(int nrows, const T* __restrict__ p0, int n0, int64_t s0, T a0, const T* __restrict__ p1, int n1, int64_t s1_, T a1,
+                                                      const T* __restrict__ v0, T b0, const T* __restrict__ v1, T b1, T* __restrict__ out,
+                                                      const T* __restrict__ dotv, double* __restrict__ partial, const CgState* __restrict__ st) {
+    if (st && st->done) return;
+    __shared__ double sh[4];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double dot = 0.0;
+    if (row < nrows) {
+        T s = T(0);
+        for (int b = 0; b < n0; ++b) s += p0[(int64_t)b * s0 + row];
+        T r = a0 * s;
+        if (p1) { T s1 = T(0); for (int b = 0; b < n1; ++b) s1 += p1[(int64_t)b * s1_ + row]; r += a1 * s1; }
+        if (v0) r += b0 * v0[row];
+        if (v1) r += b1 * v1[row];
+        out[row] = r;
+        if (dotv) dot = (double)dotv[row] * (double)r;
+    }
+    if (partial) {
+        const double tot = block_sum_256(dot, sh);
+        if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    }
+}
+
 // r = b - c, u = 0, partial ||r||^2
 template <typename T>
 __global__ __launch_bounds__(256) void k_cg_init(int n, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ r,
@@ -180,7 +339,12 @@ __global__ __launch_bounds__(256) void k_axpby(int n, T a, const T* __restrict__
     if (i < n) out[i] = a * x[i] + b * y[i];
 }
 
-struct Csr { int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int lpr = 16; int* rb = nullptr; int nblocks = 0; };
+struct Csr {
+    int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int lpr = 16; int* rb = nullptr; int nblocks = 0;
+    // column-blocked copy (k_spmv_blk): nblk CSR blocks back to back; used when `blocked`
+    bool blocked = false; int ncols = 0, nblk = 0, wpb = 0; int* brp = nullptr; unsigned short* bci = nullptr; void* bva = nullptr;
+    int* task_ptr = nullptr; int4* tasks = nullptr; int per = 1, lpr4 = 0; void* partial = nullptr;
+};
 
 int pick_lpr(int64_t nnz, int nrows) {
     const double avg = nrows > 0 ? (double)nnz / nrows : 0.0;
@@ -190,9 +354,9 @@ int pick_lpr(int64_t nnz, int nrows) {
 }
 
 template <typename T> struct SparseSolver : SolverBase {
-    Csr A, At, P;
+    Csr A, At, P, PA;   // PA = [P; A] stacked, column-blocked only: P u and A u of the CG operator from ONE pass over u
     T *q = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr;
-    T *xx = nullptr, *zz = nullptr, *w = nullptr, *tt = nullptr, *cu = nullptr, *cr = nullptr, *cc = nullptr, *tm = nullptr;
+    T *xx = nullptr, *zz = nullptr, *w = nullptr, *tt = nullptr, *cu = nullptr, *cu2 = nullptr, *cr = nullptr, *cc = nullptr, *tm = nullptr;
     T *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
     double *part_uc = nullptr, *part_rr = nullptr; CgState* state = nullptr; CgState* state_host = nullptr;
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
@@ -200,8 +364,65 @@ template <typename T> struct SparseSolver : SolverBase {
     double eps_pcg = 1e-6; int itr_pcg = 1000;
     int cat_spmv, cat_op, cat_vec, cat_chk;
 
-    void upload_csr(Csr& M, int nrows, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
+    // column-blocked copy for k_spmv_blk: per block a CSR with 16-bit local column indices + its task list
+    void build_blocked(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
+        constexpr int CB = BlkOf<T>::CB;
+        const int nrows = M.nrows, nblk = (ncols + CB - 1) / CB;
+        std::vector<int> brp((size_t)nblk * (nrows + 1), 0);
+        for (int r = 0; r < nrows; ++r)
+            for (int k = rp[r]; k < rp[r + 1]; ++k) brp[(size_t)(ci[k] / CB) * (nrows + 1) + r + 1]++;
+        int64_t run = 0;                                             // blocks back to back, rows in order inside a block
+        for (int b = 0; b < nblk; ++b) {
+            int* q_ = &brp[(size_t)b * (nrows + 1)];
+            int64_t acc = run;
+            for (int r = 0; r <= nrows; ++r) { const int cnt = q_[r]; q_[r] = (int)(acc += (r ? cnt : 0)); }
+            run = acc;
+        }
+        std::vector<unsigned short> bci((size_t)std::max<int64_t>(M.nnz, 1));
+        std::vector<T> bva((size_t)std::max<int64_t>(M.nnz, 1));
+        {
+            std::vector<int> pos((size_t)nblk * nrows);
+            for (int b = 0; b < nblk; ++b) for (int r = 0; r < nrows; ++r) pos[(size_t)b * nrows + r] = brp[(size_t)b * (nrows + 1) + r];
+            for (int r = 0; r < nrows; ++r)
+                for (int k = rp[r]; k < rp[r + 1]; ++k) {
+                    const int b = ci[k] / CB; int& w_ = pos[(size_t)b * nrows + r];
+                    bci[w_] = (unsigned short)(ci[k] - b * CB); bva[w_] = (T)va[k]; ++w_;
+                }
+        }
+        std::vector<int> tptr(nblk + 1, 0); std::vector<int4> tk;
+        for (int b = 0; b < nblk; ++b) {
+            const int* q_ = &brp[(size_t)b * (nrows + 1)];
+            int start = 0;
+            for (int r = 0; r < nrows; ++r) {
+                if ((q_[r + 1] - q_[start] > BCHUNK || r - start >= BROWS - 1) && r > start) { tk.push_back(make_int4(start, r, q_[start], q_[r])); start = r; }
+                if (q_[r + 1] - q_[start] > BCHUNK) { tk.push_back(make_int4(r, r + 1, q_[r], q_[r + 1])); start = r + 1; }   // single long row
+            }
+            if (start < nrows) tk.push_back(make_int4(start, nrows, q_[start], q_[nrows]));
+            tptr[b + 1] = (int)tk.size();
+        }
+        M.ncols = ncols; M.nblk = nblk;
+        int maxt = 1; for (int b = 0; b < nblk; ++b) maxt = std::max(maxt, tptr[b + 1] - tptr[b]);
+        M.wpb = std::max(1, std::min(maxt, (512 + nblk - 1) / nblk));   // about two workgroups per CU over the launch
+        M.wpb = std::max(M.wpb, (maxt + BMAXT - 1) / BMAXT);            // at most BMAXT tasks per workgroup
+        M.per = (maxt + M.wpb - 1) / M.wpb;
+        M.lpr4 = (M.nnz <= (int64_t)8 * nrows * nblk) ? 1 : 0;          // short row segments: 4 lanes per row
+        M.brp = dalloc<int>((int64_t)brp.size()); M.bci = dalloc<unsigned short>((int64_t)bci.size()); M.bva = dalloc<T>((int64_t)bva.size());
+        M.task_ptr = dalloc<int>(nblk + 1); M.tasks = dalloc<int4>((int64_t)tk.size() + 1);
+        M.partial = dalloc<T>((int64_t)nblk * nrows);
+        HIPC(hipMemcpy(M.brp, brp.data(), sizeof(int) * brp.size(), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(M.bci, bci.data(), sizeof(unsigned short) * bci.size(), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(M.bva, bva.data(), sizeof(T) * bva.size(), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(M.task_ptr, tptr.data(), sizeof(int) * tptr.size(), hipMemcpyHostToDevice));
+        if (!tk.empty()) HIPC(hipMemcpy(M.tasks, tk.data(), sizeof(int4) * tk.size(), hipMemcpyHostToDevice));
+        M.blocked = true;
+    }
+    void upload_csr(Csr& M, int nrows, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
         M.nrows = nrows; M.nnz = (int64_t)ci.size(); M.lpr = pick_lpr(M.nnz, nrows);
+        {   // LDS-resident x pays once the gathers dominate; QPS_SPMV_BLOCKED = 1 / 0 forces the choice
+            const char* e = getenv("QPS_SPMV_BLOCKED");
+            const bool want = e ? atoi(e) != 0 : M.nnz >= 200000;
+            if (want && nrows > 0 && ncols > 0) build_blocked(M, ncols, rp, ci, va);
+        }
         M.rp = dalloc<int>(nrows + 1); M.ci = dalloc<int>(M.nnz); M.va = dalloc<T>(M.nnz);
         HIPC(hipMemcpy(M.rp, rp.data(), sizeof(int) * (nrows + 1), hipMemcpyHostToDevice));
         {   // row blocks of the CSR-stream kernel: consecutive rows with <= STREAM_NNZ non-zeros; a longer row stands alone
@@ -255,16 +476,27 @@ template <typename T> struct SparseSolver : SolverBase {
             for (int64_t j = 0; j < n; ++j)
                 for (int k = atrp[j]; k < atrp[j + 1]; ++k) { const int r = atci[k]; aci[pos[r]] = (int)j; ava[pos[r]] = atva[k]; pos[r]++; }
         }
-        upload_csr(P, (int)n, prp, pci, pva);
-        upload_csr(At, (int)n, atrp, atci, atva);
-        upload_csr(A, (int)m, arp, aci, ava);
+        upload_csr(P, (int)n, (int)n, prp, pci, pva);
+        upload_csr(At, (int)n, (int)m, atrp, atci, atva);
+        upload_csr(A, (int)m, (int)n, arp, aci, ava);
+        const char* fuse_env = getenv("QPS_SPMV_FUSEPA");                 // 0: keep P, A, A' as three separate blocked products
+        if (m > 0 && P.blocked && A.blocked && At.blocked && pnnz + annz < 2000000000LL && !(fuse_env && atoi(fuse_env) == 0)) {
+            std::vector<int> srp((size_t)(n + m + 1)), sci; std::vector<double> sva;
+            sci.reserve((size_t)(pnnz + annz)); sva.reserve((size_t)(pnnz + annz));
+            sci.insert(sci.end(), pci.begin(), pci.end()); sci.insert(sci.end(), aci.begin(), aci.end());
+            sva.insert(sva.end(), pva.begin(), pva.end()); sva.insert(sva.end(), ava.begin(), ava.end());
+            for (int64_t i = 0; i <= n; ++i) srp[i] = prp[i];
+            for (int64_t i = 1; i <= m; ++i) srp[n + i] = (int)pnnz + arp[i];
+            PA.nrows = (int)(n + m); PA.nnz = pnnz + annz;
+            build_blocked(PA, (int)n, srp, sci, sva);
+        }
         const int64_t nn = n + 64, mm = m + 64;
         q = dalloc<T>(nn); x = dalloc<T>(nn); xp = dalloc<T>(nn); xx = dalloc<T>(nn); tt = dalloc<T>(nn);
-        cu = dalloc<T>(nn); cr = dalloc<T>(nn); cc = dalloc<T>(nn); Px = dalloc<T>(nn); Aty = dalloc<T>(nn);
+        cu = dalloc<T>(nn); cu2 = dalloc<T>(nn); cr = dalloc<T>(nn); cc = dalloc<T>(nn); Px = dalloc<T>(nn); Aty = dalloc<T>(nn);
         l = dalloc<T>(mm); u = dalloc<T>(mm); z = dalloc<T>(mm); zp = dalloc<T>(mm); y = dalloc<T>(mm); zz = dalloc<T>(mm);
         w = dalloc<T>(mm); tm = dalloc<T>(mm); Ax = dalloc<T>(mm);
         nb_n = (int)((n + 255) / 256);
-        part_uc = dalloc<double>(std::max(At.nblocks, P.nblocks) + 64); part_rr = dalloc<double>(nb_n + 64);
+        part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n) + 64); part_rr = dalloc<double>(nb_n + 64);
         state = reinterpret_cast<CgState*>(dalloc<double>(16));
         HIPC(hipHostMalloc((void**)&state_host, sizeof(CgState)));
         scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
@@ -277,10 +509,18 @@ template <typename T> struct SparseSolver : SolverBase {
         cat_op = prof.category("cg_iteration(A u, P u + rho A'. + sigma u, axpys)", spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m) + spmv_bytes(P, (int)n) + s * 10.0 * n);
         cat_vec = prof.category("admm_update", s * (3.0 * n + 7.0 * m));
         cat_chk = prof.category("check_convergence", spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m) + spmv_bytes(P, (int)n));
+        // The CSR arrays went up with synchronous hipMemcpy from pageable memory: that returns once the data is staged, the DMA
+        // may still be running on the null stream, and the solver stream is not ordered against it.
+        HIPC(hipDeviceSynchronize());
     }
     ~SparseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
+        if (cu2) (void)hipFree(cu2);
+        for (Csr* M_ : {&A, &At, &P, &PA}) {
+            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial};
+            for (void* p : bp) if (p) (void)hipFree(p);
+        }
         void* ptrs[] = {A.rp, A.ci, A.va, A.rb, At.rp, At.ci, At.va, At.rb, P.rp, P.ci, P.va, P.rb, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
                         Ax, Px, Aty, part_uc, part_rr, state, scratch, res_dev, stage};
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -292,35 +532,73 @@ template <typename T> struct SparseSolver : SolverBase {
     void spmv(const Csr& M, const T* xin, T* out, T a, const T* v0, T b0, const T* v1, T b1, const CgState* stt,
               const T* dotv = nullptr, double* partial = nullptr) {
         if (M.nblocks <= 0) return;
+        if (M.blocked) {
+            spmv_blk(M, xin, stt);
+            hipLaunchKernelGGL((k_spmv_combine<T>), dim3((M.nrows + 255) / 256), dim3(256), 0, st, M.nrows, static_cast<const T*>(M.partial), M.nblk, (int64_t)M.nrows, a,
+                               (const T*)nullptr, 0, (int64_t)0, T(0), v0, b0, v1, b1, out, dotv, partial, stt);
+            return;
+        }
         hipLaunchKernelGGL((k_spmv_stream<T>), dim3(M.nblocks), dim3(256), 0, st, M.rb, M.rp, M.ci, static_cast<const T*>(M.va), xin, out, a,
                            v0, b0, v1, b1, dotv, partial, stt);
     }
+    // partial[b][row] of M * x
+    void spmv_blk(const Csr& M, const T* xin, const CgState* stt, CgFuse<T> fu = CgFuse<T>()) {
+        if (M.lpr4) hipLaunchKernelGGL((k_spmv_blk<T, 4>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, M.nrows, M.ncols, M.task_ptr, M.tasks, M.per, M.brp, M.bci,
+                                       static_cast<const T*>(M.bva), xin, static_cast<T*>(M.partial), stt, fu);
+        else hipLaunchKernelGGL((k_spmv_blk<T, 8>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, M.nrows, M.ncols, M.task_ptr, M.tasks, M.per, M.brp, M.bci,
+                                static_cast<const T*>(M.bva), xin, static_cast<T*>(M.partial), stt, fu);
+    }
+    int dot_parts(const Csr& M) const { return M.blocked ? (M.nrows + 255) / 256 : M.nblocks; }
     // c = P u + rho A'(A u) + sigma u (LinearSystemSolvers.jl:152-157) as three streamed SpMVs; optional partials of dot(u, c)
     void op_reduced(const T* uin, T* cout, double rho, double sigma, double* partial, const CgState* stt) {
+        if (m > 0 && P.blocked && A.blocked && At.blocked) {
+            // three blocked products; P u and A'(A u) share one combine launch that also forms the dot partials
+            spmv_blk(P, uin, stt);
+            spmv(A, uin, tm, T(1), nullptr, T(0), nullptr, T(0), stt);
+            spmv_blk(At, tm, stt);
+            hipLaunchKernelGGL((k_spmv_combine<T>), dim3(nb_n), dim3(256), 0, st, (int)n, static_cast<const T*>(P.partial), P.nblk, (int64_t)n, T(1),
+                               static_cast<const T*>(At.partial), At.nblk, (int64_t)n, (T)rho, uin, (T)sigma, (const T*)nullptr, T(0), cout, partial ? uin : nullptr, partial, stt);
+            return;
+        }
         spmv(P, uin, cout, T(1), uin, (T)sigma, nullptr, T(0), stt, (m > 0) ? nullptr : uin, (m > 0) ? nullptr : partial);
         if (m > 0) {
             spmv(A, uin, tm, T(1), nullptr, T(0), nullptr, T(0), stt);
             spmv(At, tm, cout, (T)rho, cout, T(1), nullptr, T(0), stt, uin, partial);
         }
     }
-    int op_parts() const { return m > 0 ? At.nblocks : P.nblocks; }
+    int op_parts() const { return (m > 0 && P.blocked && A.blocked && At.blocked) ? nb_n : (m > 0 ? dot_parts(At) : dot_parts(P)); }
 
     // IterativeSolvers.cg!(xx, Op, tt; abstol = eps_pcg, maxiter = itr_pcg), xx warm started
     int cg(double rho, double sigma) {
         CgState* slot[2] = {state, state + 1};
         int cur = 0;
         op_reduced(xx, cc, rho, sigma, nullptr, nullptr);
-        hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_n), dim3(256), 0, st, (int)n, tt, cc, cr, cu, part_rr);
+        T* ub[2] = {cu, cu2}; int ui = 0;                            // ub[ui] = current direction u
+        hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_n), dim3(256), 0, st, (int)n, tt, cc, cr, ub[ui], part_rr);
         hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur], eps_pcg, itr_pcg);
         int launched = 0, batch = std::max(1, std::min(last_cg + 1, 64));
         for (;;) {
             for (int b = 0; b < batch; ++b) {
                 ProfScope ps(prof, cat_op, 2);
                 // fold the previous iteration's ||r||^2, publish the scalars into the other slot, u = r + beta u
-                hipLaunchKernelGGL((k_cg_next_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_n, part_rr, cr, cu, slot[cur], slot[cur ^ 1], b == 0 ? 1 : 0);
-                cur ^= 1;
-                op_reduced(cu, cc, rho, sigma, part_uc, slot[cur]);
-                hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, op_parts(), part_uc, cu, cc, xx, cr, part_rr, slot[cur]);
+                if (PA.blocked) {
+                    // [P; A] u with u = r + beta u_old formed while the x blocks are loaded; then A'(A u); ONE combine for c and dot(u, c)
+                    CgFuse<T> fu; fu.r = cr; fu.uold = ub[ui]; fu.unew = ub[ui ^ 1]; fu.part_rr = part_rr; fu.nparts = nb_n;
+                    fu.cur = slot[cur]; fu.nxt = slot[cur ^ 1]; fu.first = b == 0 ? 1 : 0;
+                    spmv_blk(PA, cr, nullptr, fu);
+                    cur ^= 1; ui ^= 1;
+                    const T* pp = static_cast<const T*>(PA.partial);
+                    hipLaunchKernelGGL((k_spmv_combine<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (int)m, pp + n, PA.nblk, (int64_t)(n + m), T(1),
+                                       (const T*)nullptr, 0, (int64_t)0, T(0), (const T*)nullptr, T(0), (const T*)nullptr, T(0), tm, (const T*)nullptr, (double*)nullptr, slot[cur]);
+                    spmv_blk(At, tm, slot[cur]);
+                    hipLaunchKernelGGL((k_spmv_combine<T>), dim3(nb_n), dim3(256), 0, st, (int)n, pp, PA.nblk, (int64_t)(n + m), T(1),
+                                       static_cast<const T*>(At.partial), At.nblk, (int64_t)n, (T)rho, ub[ui], (T)sigma, (const T*)nullptr, T(0), cc, ub[ui], part_uc, slot[cur]);
+                } else {
+                    hipLaunchKernelGGL((k_cg_next_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_n, part_rr, cr, ub[ui], slot[cur], slot[cur ^ 1], b == 0 ? 1 : 0);
+                    cur ^= 1;
+                    op_reduced(ub[ui], cc, rho, sigma, part_uc, slot[cur]);
+                }
+                hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, PA.blocked ? nb_n : op_parts(), part_uc, ub[ui], cc, xx, cr, part_rr, slot[cur]);
             }
             hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur]);   // fold the last iteration of the batch
             launched += batch;

@@ -68,6 +68,9 @@ template <typename T> inline T* dalloc(int64_t count) {
     T* p = nullptr; if (count < 64) count = 64;
     HIPC(hipMalloc((void**)&p, sizeof(T) * (size_t)count));
     HIPC(hipMemset(p, 0, sizeof(T) * (size_t)count));
+    // The fill runs on the null stream and may still be in flight when hipMemset returns; the solver streams are
+    // non-blocking (not ordered against the null stream), so wait here: a kernel must never race the zero fill.
+    HIPC(hipStreamSynchronize(nullptr));
     return p;
 }
 

@@ -265,10 +265,12 @@ SPARSE_CASES = [(ProblemClass.randomQp, 200, 0), (ProblemClass.isotonicRegressio
                 (ProblemClass.randomQp, 2000, 3000)]
 
 
+@pytest.mark.parametrize("blocked", ["0", "1"])      # CSR-stream SpMV (gathers through L1/L2) / column-blocked SpMV (x block in LDS)
 @pytest.mark.parametrize("pc,n,m", SPARSE_CASES)
-def test_cg_path_iterates_match_oracle(gpu, c_oracle, pc, n, m):
+def test_cg_path_iterates_match_oracle(gpu, c_oracle, monkeypatch, pc, n, m, blocked):
     """With the inner tolerance driven to 1e-13 both CG implementations solve the linear system to fp64 accuracy, so the
     ADMM iterates must agree tightly (the summation order inside the SpMVs differs)."""
+    monkeypatch.setenv("QPS_SPMV_BLOCKED", blocked)   # read when the handle is created
     P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 80 + int(pc)))
     with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
         for K in (25, 50):
@@ -279,6 +281,24 @@ def test_cg_path_iterates_match_oracle(gpu, c_oracle, pc, n, m):
                                     epsPcg=1e-13, numItrPcg=5000)
             assert info["cgIterations"] > 0
             assert rel(x, xo) <= 1e-7 and rel(z, io["z"]) <= 1e-7 and rel(y, io["y"]) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_cg_path_column_blocked_spmv_with_several_blocks(gpu, c_oracle, monkeypatch, dtype):
+    """n = 9000, m = 16000: A has two column blocks, A' three (fp64: 7168 columns per block; one / two in fp32), so the partial sums per block,
+    the fused sum-while-loading of A u inside the A' product and the one-launch combine are all exercised."""
+    from quadraticprogramsolver_amd.generator import GenerateSparseBenchmarkQP
+    monkeypatch.setenv("QPS_SPMV_BLOCKED", "1")       # (auto-selected from 200 k non-zeros per matrix; P has 169 k here)
+    n, m = 9000, 16000
+    P, q, A, l, u = GenerateSparseBenchmarkQP(n, m, densityA=2e-3, seed=99)
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg", dtype=dtype) as prob:
+        x = np.zeros(n); info = {}
+        prob.solve(x, numIterations=20, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, ϵPcg=1e-13 if dtype == "f64" else 1e-5, numItrPcg=3000, info=info)
+        z, y = prob.dual()
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_CG_MATFREE, epsPcg=1e-13, numItrPcg=3000)
+    tol = 1e-7 if dtype == "f64" else 2e-3
+    assert info["cgIterations"] > 0
+    assert rel(x, xo) <= tol and rel(z, io["z"]) <= tol and rel(y, io["y"]) <= 10 * tol
 
 
 @pytest.mark.parametrize("pc,n,m", SPARSE_CASES[:4])

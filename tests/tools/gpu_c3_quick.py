@@ -16,6 +16,7 @@ for k in prob.kernel_times():
     us = k['seconds'] / k['launches'] * 1e6
     print(f"   {k['name']:52s} {us:9.1f} us/launch  {k['algo_bytes']/us/1e6:8.3f} TB/s algorithmic  ({k['launches']} launches)")
 prob.set_profiling(0)
+if os.environ.get("QPS_SKIP_EPS"): sys.exit(0)
 x = np.zeros(n); t = time.time()
 flag = prob.solve(x, numIterations=20000, ρ=0.1, adptΡ=True, info=info)
 print(f"time-to-eps(1e-6): flag {int(flag)} its {info['iterations']} cg {info['cgIterations']} loop {info['tLoop']*1e3:.1f} ms")
