@@ -237,9 +237,15 @@ __global__ __launch_bounds__(256) void k_spmv_combine(int nrows, const T* __rest
     double dot = 0.0;
     if (row < nrows) {
         T s = T(0);
-        for (int b = 0; b < n0; ++b) s += p0[(int64_t)b * s0 + row];
+#pragma unroll 8
+        for (int b = 0; b < n0; ++b) s += p0[(int64_t)b * s0 + row];                      // independent loads, several in flight
         T r = a0 * s;
-        if (p1) { T s1 = T(0); for (int b = 0; b < n1; ++b) s1 += p1[(int64_t)b * s1_ + row]; r += a1 * s1; }
+        if (p1) {
+            T s1 = T(0);
+#pragma unroll 8
+            for (int b = 0; b < n1; ++b) s1 += p1[(int64_t)b * s1_ + row];
+            r += a1 * s1;
+        }
         if (v0) r += b0 * v0[row];
         if (v1) r += b1 * v1[row];
         out[row] = r;
@@ -402,7 +408,9 @@ template <typename T> struct SparseSolver : SolverBase {
         }
         M.ncols = ncols; M.nblk = nblk;
         int maxt = 1; for (int b = 0; b < nblk; ++b) maxt = std::max(maxt, tptr[b + 1] - tptr[b]);
-        M.wpb = std::max(1, std::min(maxt, (512 + nblk - 1) / nblk));   // about two workgroups per CU over the launch
+        static const int wgs_env = [] { const char* e = getenv("QPS_SPMV_WGS"); return e ? atoi(e) : 0; }();
+        const int wgs = wgs_env > 0 ? wgs_env : 512;
+        M.wpb = std::max(1, std::min(maxt, (wgs + nblk - 1) / nblk));   // about two workgroups per CU over the launch
         M.wpb = std::max(M.wpb, (maxt + BMAXT - 1) / BMAXT);            // at most BMAXT tasks per workgroup
         M.per = (maxt + M.wpb - 1) / M.wpb;
         M.lpr4 = (M.nnz <= (int64_t)8 * nrows * nblk) ? 1 : 0;          // short row segments: 4 lanes per row
