@@ -135,6 +135,69 @@ __global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restri
 // thread (i, g) keeps the 16 entries a[i][16g .. 16g+15] in registers.  The 16 columns of a panel live in ONE wave, so
 // the panel is factorised with wave64 shuffles only (no LDS, no barrier); the finished panel is then published through
 // LDS and the waves to its right apply the rank-16 update.  4 panels => 8 barriers per block instead of 128.
+// Broadcast of lane `L` (a compile-time constant once the panel loops are unrolled) through v_readlane: a few cycles, where
+// __shfl's ds_bpermute costs an LDS round trip -- the factorisation of a diagonal block is one long dependent chain of them.
+template <int L> __device__ __forceinline__ double lane_bcast(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), L);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int L> __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
+// 1/sqrt(d) to working precision: hardware estimate + two Newton steps (no division, no sqrt sequence on the critical path)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+__device__ __forceinline__ float rsqrt_nr(float d) {
+    float y = __builtin_amdgcn_rsqf(d);
+    y = y * (1.5f - 0.5f * d * y * y);
+    return y;
+}
+
+template <typename T, int P, int K> struct PotrfCol {
+    static __device__ __forceinline__ void run(T (&a)[16], int i, int kb, int* fail) {
+        T d = lane_bcast<16 * P + K>(a[K]);
+        if (!(d > T(0))) { if (i == 0) atomicCAS(fail, 0, kb * 64 + 16 * P + K + 1); d = T(1); }
+        const T rs = rsqrt_nr(d);
+        a[K] *= rs;                                          // l_ik for i >= k (row k itself: d * rs = sqrt(d))
+        PotrfCol<T, P, K>::template update<K + 1>(a);
+        PotrfCol<T, P, K + 1>::run(a, i, kb, fail);
+    }
+    template <int J> static __device__ __forceinline__ void update(T (&a)[16]) {
+        if constexpr (J < 16) {
+            const T ljk = lane_bcast<16 * P + J>(a[K]);
+            a[J] -= a[K] * ljk;
+            update<J + 1>(a);
+        }
+    }
+};
+template <typename T, int P> struct PotrfCol<T, P, 16> { static __device__ __forceinline__ void run(T (&)[16], int, int, int*) {} };
+
+template <typename T, int P>
+__device__ __forceinline__ void potrf_panel(T (&a)[16], T (*Lp)[17], int i, int g, int kb, int* fail) {
+    if (g == P) {                                            // wave-uniform
+        PotrfCol<T, P, 0>::run(a, i, kb, fail);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lp[i][k] = a[k];
+    }
+    __syncthreads();
+    if (g > P) {
+        T li[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) li[k] = Lp[i][k];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += li[k] * Lp[16 * g + jj][k];   // same address for all lanes: broadcast
+            a[jj] -= s;
+        }
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail, int64_t sM) {
     __shared__ T Lp[64][17];
@@ -144,39 +207,10 @@ __global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, 
     T a[16];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) a[jj] = blk[(int64_t)i * ld + 16 * g + jj];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (g == p) {                                        // wave-uniform
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                T d = __shfl(a[k], 16 * p + k, 64);
-                if (!(d > T(0))) { if (i == 0) atomicCAS(fail, 0, kb * 64 + 16 * p + k + 1); d = T(1); }
-                const T rs = T(1) / sqrt(d);
-                a[k] *= rs;                                  // l_ik for i >= k (row k itself: d * rs = sqrt(d))
-#pragma unroll
-                for (int j = k + 1; j < 16; ++j) {
-                    const T ljk = __shfl(a[k], 16 * p + j, 64);
-                    a[j] -= a[k] * ljk;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Lp[i][k] = a[k];
-        }
-        __syncthreads();
-        if (g > p) {
-            T li[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) li[k] = Lp[i][k];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                T s = T(0);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) s += li[k] * Lp[16 * g + jj][k];   // same address for all lanes: broadcast
-                a[jj] -= s;
-            }
-        }
-        __syncthreads();
-    }
+    potrf_panel<T, 0>(a, Lp, i, g, kb, fail);
+    potrf_panel<T, 1>(a, Lp, i, g, kb, fail);
+    potrf_panel<T, 2>(a, Lp, i, g, kb, fail);
+    potrf_panel<T, 3>(a, Lp, i, g, kb, fail);
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const int j = 16 * g + jj;
@@ -224,20 +258,21 @@ __global__ __launch_bounds__(256) void k_inv64(const T* __restrict__ L, int64_t 
 template <typename T>
 __global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld, int kb, int nrows, int64_t sM) {
     __shared__ T Ls[64][65];
+    __shared__ T Xs[64][65];
     __shared__ T rdiag[64];
     const int t = threadIdx.x;
     M += (int64_t)blockIdx.y * sM;
     const T* L11 = M + (int64_t)kb * 64 * ld + kb * 64;
-    for (int r = 0; r < 64; ++r) Ls[r][t] = L11[(int64_t)r * ld + t];
+    T* a0 = M + (int64_t)((kb + 1) * 64 + blockIdx.x * 64) * ld + kb * 64;      // this workgroup's 64 x 64 tile of A21 (nrows is a multiple of 64)
+    // both tiles through LDS with lanes along a row (one 512-B segment per load instruction); a thread then owns one row
+#pragma unroll 16
+    for (int r = 0; r < 64; ++r) { Ls[r][t] = L11[(int64_t)r * ld + t]; Xs[r][t] = a0[(int64_t)r * ld + t]; }
     __syncthreads();
     rdiag[t] = T(1) / Ls[t][t];
     __syncthreads();
-    const int row = blockIdx.x * 64 + t;
-    if (row >= nrows) return;
-    T* ar = M + (int64_t)((kb + 1) * 64 + row) * ld + kb * 64;
     T x[64];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) x[j] = ar[j];
+    for (int j = 0; j < 64; ++j) x[j] = Xs[t][j];
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
         T s = x[j];
@@ -246,7 +281,11 @@ __global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld
         x[j] = s * rdiag[j];
     }
 #pragma unroll
-    for (int j = 0; j < 64; ++j) ar[j] = x[j];
+    for (int j = 0; j < 64; ++j) Xs[t][j] = x[j];
+    __syncthreads();
+#pragma unroll 16
+    for (int r = 0; r < 64; ++r) a0[(int64_t)r * ld + t] = Xs[r][t];
+    (void)nrows;
 }
 
 // S lower <- L lower with the 64-blocks on the diagonal replaced by their inverses; S upper <- 0
