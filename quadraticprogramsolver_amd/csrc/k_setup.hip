@@ -30,13 +30,10 @@ constexpr int GK = 16;    // K depth per LDS stage
 constexpr int GLD = 80;   // LDS row stride (elements): k-groups of a fragment read land 32 banks apart
 
 // 64 x 64 C tile per 256-thread workgroup; waves in a 2 x 2 grid, each wave 2 x 2 MFMA 16 x 16 tiles.
+// tile != nullptr: the finished C tile goes to that LDS array (row stride 65) INSTEAD of global memory
 template <typename T, bool AK, bool BK>
-__global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-                                              int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
-                                              int64_t sA, int64_t sB, int64_t sC, int ktri) {
-    const int bj = blockIdx.x, bi = blockIdx.y;
-    if (lower_only && bj > bi) return;
-    A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
+__device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T beta,
+                                          T* __restrict__ C, int64_t ldc, int ktri, int bi, int bj, T (*tile)[65]) {
     __shared__ T As[GK][GLD];
     __shared__ T Bs[GK][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,8 +84,18 @@ __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restric
                 T* cp = C + (int64_t)row * ldc + col;
                 T v = alpha * acc[a][b][r];
                 if (beta != T(0)) v += beta * (*cp);
-                *cp = v;
+                if (tile) tile[row - i0][col - j0] = v;
+                else *cp = v;
             }
+}
+template <typename T, bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                              int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
+                                              int64_t sA, int64_t sB, int64_t sC, int ktri) {
+    const int bj = blockIdx.x, bi = blockIdx.y;
+    if (lower_only && bj > bi) return;
+    A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
+    gemm_tile<T, AK, BK>(K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bi, bj, nullptr);
 }
 
 // column-major double src (rows x cols) -> row-major T dst (ld ldd), via a 64 x 64 LDS transpose tile; dst padding is
@@ -198,15 +205,14 @@ __device__ __forceinline__ void potrf_panel(T (&a)[16], T (*Lp)[17], int i, int 
     __syncthreads();
 }
 
+// src: the block to factorise, either in place in global memory (src == nullptr) or in an LDS tile (row stride 65)
 template <typename T>
-__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail, int64_t sM) {
+__device__ __forceinline__ void potrf_block(T* __restrict__ blk, int64_t ld, int kb, int* __restrict__ fail, T (*src)[65]) {
     __shared__ T Lp[64][17];
     const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
-    M += (int64_t)blockIdx.x * sM; fail += blockIdx.x;                            // batched: one workgroup per QP
-    T* blk = M + (int64_t)kb * 64 * ld + kb * 64;
     T a[16];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) a[jj] = blk[(int64_t)i * ld + 16 * g + jj];
+    for (int jj = 0; jj < 16; ++jj) a[jj] = src ? src[i][16 * g + jj] : blk[(int64_t)i * ld + 16 * g + jj];
     potrf_panel<T, 0>(a, Lp, i, g, kb, fail);
     potrf_panel<T, 1>(a, Lp, i, g, kb, fail);
     potrf_panel<T, 2>(a, Lp, i, g, kb, fail);
@@ -215,6 +221,29 @@ __global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, 
     for (int jj = 0; jj < 16; ++jj) {
         const int j = 16 * g + jj;
         blk[(int64_t)i * ld + j] = (j <= i) ? a[jj] : T(0);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_potrf64(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail, int64_t sM) {
+    M += (int64_t)blockIdx.x * sM; fail += blockIdx.x;                            // batched: one workgroup per QP
+    potrf_block<T>(M + (int64_t)kb * 64 * ld + kb * 64, ld, kb, fail, nullptr);
+}
+// Trailing update of step kb (A22 -= L21 L21', lower tiles) with the factorisation of the NEXT diagonal block fused in: the
+// workgroup that owns tile (0, 0) keeps its finished tile in LDS and factorises it while the other tiles are still being
+// updated -- one launch less on the chain of dependent launches per 64-column step.
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_potrf(T* __restrict__ M, int64_t ld, int kb, int* __restrict__ fail, int64_t sM) {
+    const int bj = blockIdx.x, bi = blockIdx.y;
+    if (bj > bi) return;
+    M += (int64_t)blockIdx.z * sM; fail += blockIdx.z;
+    __shared__ T tile[64][65];
+    const T* A21 = M + (int64_t)(kb + 1) * 64 * ld + kb * 64;
+    T* A22 = M + (int64_t)(kb + 1) * 64 * ld + (kb + 1) * 64;
+    const bool diag0 = (bi == 0 && bj == 0);                                      // workgroup-uniform
+    gemm_tile<T, true, true>(64, T(-1), A21, ld, A21, ld, T(1), A22, ld, 0, bi, bj, diag0 ? tile : nullptr);
+    if (diag0) {
+        __syncthreads();
+        potrf_block<T>(A22, ld, kb + 1, fail, tile);
     }
 }
 
@@ -348,16 +377,14 @@ template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* 
     (void)hipMemsetAsync(fail_dev, 0, sizeof(int) * batch, st);
     const int nblk = NP / 64;
     const int64_t sM = (int64_t)NP * NP, sD = (int64_t)nblk * 4096;
+    hipLaunchKernelGGL((k_potrf64<T>), dim3(batch), dim3(256), 0, st, M, (int64_t)NP, 0, fail_dev, sM);
     for (int kb = 0; kb < nblk; ++kb) {
-        hipLaunchKernelGGL((k_potrf64<T>), dim3(batch), dim3(256), 0, st, M, (int64_t)NP, kb, fail_dev, sM);
         const int rem = NP - (kb + 1) * 64;
         if (rem <= 0) break;
         // L21 = A21 * inv(L11)'  by forward substitution, one thread per row
         hipLaunchKernelGGL((k_trsm_panel<T>), dim3(rem / 64, batch), dim3(64), 0, st, M, (int64_t)NP, kb, rem, sM);
-        // A22 -= L21 * L21'  (lower tiles only)
-        T* A21 = M + (int64_t)(kb + 1) * 64 * NP + kb * 64;
-        T* A22 = M + (int64_t)(kb + 1) * 64 * NP + (kb + 1) * 64;
-        gemm<T>(st, rem, rem, 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true, batch, sM, sM, sM);
+        // A22 -= L21 * L21'  (lower tiles only) + factorisation of diagonal block kb + 1
+        hipLaunchKernelGGL((k_update_potrf<T>), dim3(rem / 64, rem / 64, batch), dim3(256), 0, st, M, (int64_t)NP, kb, fail_dev, sM);
     }
     hipLaunchKernelGGL((k_inv64<T>), dim3(nblk, batch), dim3(256), 0, st, M, (int64_t)NP, dinv, sM, sD);
 }
