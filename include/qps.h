@@ -83,8 +83,7 @@ typedef struct {
                                 1 = unfused kernels (A read twice; the literal order of LinearSystemSolvers.jl:134-139);
                                 2 = multi-launch fused loop even for small problems */
     int32_t polish;          /* additive: 0 = no polishing (what SolveQuadraticProgram.jl does, default); 1 = run the polishing step
-                                of SolveQuadraticProgram.m:289-325 after the loop with numItrPolish, delta, epsMinres, numItrMinres
-                                (dense handles) */
+                                of SolveQuadraticProgram.m:289-325 after the loop with numItrPolish, delta, epsMinres, numItrMinres */
     int32_t reserved0;
 } qps_params;
 
@@ -135,7 +134,7 @@ int32_t qps_solve(qps_handle h, double *x_inout, const qps_params *params, qps_i
 /* The polishing step alone (SolveQuadraticProgram.m:289-325; MATLAB only -- the Julia loop reserves its kwargs,
  * SolveQuadraticProgram.jl:16-17): active sets from the sign of the multiplier y (length m), reduced KKT system, iterative
  * refinement with MINRES (numItrPolish, delta, epsMinres, numItrMinres of *params).  x_inout (length n) is replaced by the
- * polished primal only when report->flag == 0.  Dense handles. */
+ * polished primal only when report->flag == 0.  Dense and CSR handles (batch handles: through qps_params.polish). */
 typedef struct {
     int32_t flag;              /* minresFlag: -1 did not run (numItrPolish <= 0), 0 converged, 1 not converged (x kept) */
     int32_t refinements;       /* bodies of the refinement loop executed (<= numItrPolish) */

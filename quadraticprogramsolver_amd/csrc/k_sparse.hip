@@ -16,6 +16,7 @@
 
 #include "qps_internal.h"
 #include "qps_kernels.h"
+#include "qps_polish.h"
 
 namespace qps {
 
@@ -679,18 +680,42 @@ template <typename T> struct SparseSolver : SolverBase {
         HIPC(hipStreamSynchronize(st));
         prof.harvest();
         const double t2 = now_s();
+        PolishReport pr;
+        if (p.polish) polish_device(p, &pr);
         download_vec(x, xh, n);
         if (info) {
             info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
             info->numRefactor = nref; info->cgIterations = (int)cg_total; info->rhoFinal = rho; info->rhoProposed = rhorho;
             info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = 0;
-            info->polishFlag = -1; info->polishIterations = 0; info->tPolish = 0;
+            info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
         }
     }
     void get_dual(double* zh, double* yh) override {
         HIPC(hipSetDevice(device));
         if (zh) download_vec(z, zh, m);
         if (yh) download_vec(y, yh, m);
+    }
+    // SolveQuadraticProgram.m:289-325 with the products of K as SpMVs (x block of length n, multiplier block of length m)
+    void polish_device(const qps_params& p, PolishReport* pr) {
+        PolishProduct<T> kmat = [&](const T* v, T delta, T* out, const T* mask, T* scratch) {
+            spmv(P, v, out, T(1), v, delta, nullptr, T(0), nullptr);                                // P v_x + delta v_x
+            if (m <= 0) return;
+            spmv(A, v, out + n, T(1), nullptr, T(0), nullptr, T(0), nullptr);                       // A v_x
+            polish_mask_rows<T>(st, (int)m, mask, v + n, delta, out + n, scratch);                  // mask . - delta mask v_lambda; scratch = mask v_lambda
+            spmv(At, scratch, out, T(1), out, T(1), nullptr, T(0), nullptr);                        // + A'(mask v_lambda)
+        };
+        polish_with<T>(st, n, m, (int)n, (int)m, q, l, u, y, x, p, pr, kmat);
+    }
+    void polish(double* xh, const double* yh, const qps_params& p, qps_polish_report* rep) override {
+        HIPC(hipSetDevice(device));
+        upload_vec(xh, x, n); upload_vec(yh, y, m);
+        PolishReport pr;
+        polish_device(p, &pr);
+        download_vec(x, xh, n);
+        if (rep) {
+            rep->flag = pr.flag; rep->refinements = pr.refinements; rep->minresIterations = pr.minresIterations;
+            rep->numActiveLower = pr.numLower; rep->numActiveUpper = pr.numUpper; rep->reserved0 = 0; rep->relres = pr.relres; rep->seconds = pr.seconds;
+        }
     }
     void linsys_init(double, double, int linsys, int) override {
         HIPC(hipSetDevice(device));

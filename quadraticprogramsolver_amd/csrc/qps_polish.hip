@@ -202,9 +202,34 @@ int minres_device(hipStream_t st, int N, const std::function<void(const T*, T, T
 
 }  // namespace
 
+template <typename T> void polish_mask_rows(hipStream_t st, int MP, const T* mask, const T* vlam, T delta, T* out_lam, T* wl) {
+    hipLaunchKernelGGL((k_pol_maskrow<T>), blocks(MP), dim3(256), 0, st, MP, mask, vlam, delta, out_lam, wl);
+}
+
 template <typename T>
 void polish_dense(hipStream_t st, int64_t n, int64_t m, int NP, int MP, const T* P, const T* A, const T* q, const T* l, const T* u, const T* y,
                   T* x, T* part, const qps_params& p, PolishReport* rep) {
+    const bool fusedA = MP > 0 && apass_proxqp_slabs<T>(NP, MP) > 0;
+    // out = K v + delta blkdiag(I, -I) v  with the multiplier block masked                         :304-305
+    PolishProduct<T> kmat = [&](const T* v, T delta, T* out, const T* mask, T* scratch) {
+        gemv_rows<T>(st, P, NP, v, out, v, T(1), delta, 0, NP, 0, NP, 0);                           // P v_x + delta v_x
+        if (MP <= 0) return;
+        if (fusedA) {
+            const int G = apass_kkt<T>(st, A, NP, NP, MP, v, v + NP, mask, delta, out + NP, part, NP);
+            colsum<T>(st, part, NP, G, out, T(1), nullptr, T(0), out, NP);                          // + A'(mask v_lambda)
+        } else {
+            gemv_rows<T>(st, A, NP, v, out + NP, nullptr, T(1), T(0), 0, MP, 0, NP, 0);             // A v_x
+            polish_mask_rows<T>(st, MP, mask, v + NP, delta, out + NP, scratch);
+            const int tiles = gemv_cols_partial<T>(st, A, NP, scratch, nullptr, T(1), T(0), part, NP, MP, NP);
+            colsum<T>(st, part, NP, tiles, out, T(1), nullptr, T(0), out, NP);
+        }
+    };
+    polish_with<T>(st, n, m, NP, MP, q, l, u, y, x, p, rep, kmat);
+}
+
+template <typename T>
+void polish_with(hipStream_t st, int64_t n, int64_t m, int NP, int MP, const T* q, const T* l, const T* u, const T* y, T* x, const qps_params& p,
+                 PolishReport* rep, const PolishProduct<T>& kmat) {
     PolishReport r;
     const double t0 = now_s();
     if (p.numItrPolish <= 0) { if (rep) *rep = r; return; }                                        // :292
@@ -220,21 +245,7 @@ void polish_dense(hipStream_t st, int64_t n, int64_t m, int NP, int MP, const T*
     int counts[2] = {0, 0};
     HIPC(hipMemcpyAsync(counts, wk.counts, sizeof(counts), hipMemcpyDeviceToHost, st));
 
-    const bool fusedA = MP > 0 && apass_proxqp_slabs<T>(NP, MP) > 0;
-    // out = K v + delta blkdiag(I, -I) v  with the multiplier block masked                         :304-305
-    std::function<void(const T*, T, T*)> matvec = [&](const T* v, T delta, T* out) {
-        gemv_rows<T>(st, P, NP, v, out, v, T(1), delta, 0, NP, 0, NP, 0);                           // P v_x + delta v_x
-        if (MP <= 0) return;
-        if (fusedA) {
-            const int G = apass_kkt<T>(st, A, NP, NP, MP, v, v + NP, mask, delta, out + NP, part, NP);
-            colsum<T>(st, part, NP, G, out, T(1), nullptr, T(0), out, NP);                          // + A'(mask v_lambda)
-        } else {
-            gemv_rows<T>(st, A, NP, v, out + NP, nullptr, T(1), T(0), 0, MP, 0, NP, 0);             // A v_x
-            hipLaunchKernelGGL((k_pol_maskrow<T>), blocks(MP), dim3(256), 0, st, MP, mask, v + NP, delta, out + NP, W[2]);
-            const int tiles = gemv_cols_partial<T>(st, A, NP, W[2], nullptr, T(1), T(0), part, NP, MP, NP);
-            colsum<T>(st, part, NP, tiles, out, T(1), nullptr, T(0), out, NP);
-        }
-    };
+    std::function<void(const T*, T, T*)> matvec = [&](const T* v, T delta, T* out) { kmat(v, delta, out, mask, W[2]); };
     HIPC(hipMemsetAsync(t, 0, sizeof(T) * (size_t)N, st));                                          // :307
     HIPC(hipMemsetAsync(tt, 0, sizeof(T) * (size_t)N, st));                                         // :308
     int flag = -1;                                                                                  // :311
@@ -254,6 +265,9 @@ void polish_dense(hipStream_t st, int64_t n, int64_t m, int NP, int MP, const T*
 }
 
 #define INST(T)                                                                                                               \
+    template void polish_mask_rows<T>(hipStream_t, int, const T*, const T*, T, T*, T*);                                       \
+    template void polish_with<T>(hipStream_t, int64_t, int64_t, int, int, const T*, const T*, const T*, const T*, T*, const qps_params&, \
+                                 PolishReport*, const PolishProduct<T>&);                                                     \
     template void polish_dense<T>(hipStream_t, int64_t, int64_t, int, int, const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, \
                                   const qps_params&, PolishReport*);
 INST(double)

@@ -104,10 +104,27 @@ def test_polish_flag_semantics_and_errors(gpu, np_oracle):
         with pytest.raises(gpu.QpsError) as e:
             prob.polish(xg, bad)
         assert e.value.status == 3
-    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:               # CSR/CG handles: not implemented, said loudly
-        with pytest.raises(gpu.QpsError) as e:
-            prob.polish(x.copy(), y)
-        assert e.value.status == 8
+
+
+@pytest.mark.parametrize("blocked", ["0", "1"])
+def test_polish_on_csr_handles_matches_restatement(gpu, np_oracle, pol, monkeypatch, blocked):
+    """CSR/CG handles run the same refinement loop with the products of K as SpMVs (stream and column-blocked kernels)."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("QPS_SPMV_BLOCKED", blocked)
+    n, m = 200, 150
+    P, q, A, l, u = problem(n, m, 5)
+    x, y = admm_state(np_oracle, P, q, A, l, u)
+    y = np.where(np.abs(y) > 1e-7, y, 0.0)
+    xr, fr, ir = pol.Polish(P, q, A, l, u, x, y, 10, 1e-6, 1e-9, 4000)
+    with gpu.QuadraticProgram(sp.csc_matrix(P), q, sp.csc_matrix(A), l, u, linsys="cg") as prob:
+        xg = x.copy()
+        rep = prob.polish(xg, y, numItrPolish=10, δ=1e-6, ϵMinres=1e-9, numItrMinres=4000)
+        # chained form on the CG loop's own state
+        x1 = np.zeros(n); i1 = {}
+        prob.solve(x1, numIterations=300, ϵAbs=1e-4, ϵRel=1e-4, ρ=0.1, adptΡ=True, polish=True, info=i1)
+    assert rep["flag"] == fr == 0 and rep["numActiveLower"] == ir["numActiveLower"] and rep["numActiveUpper"] == ir["numActiveUpper"]
+    assert np.abs(xg - xr).max() <= 1e-7 * max(1.0, np.abs(xr).max())
+    assert i1["polishFlag"] in (0, 1) and i1["polishIterations"] > 0
 
 
 def test_polish_without_constraints_is_the_unconstrained_minimiser(gpu):
