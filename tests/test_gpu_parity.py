@@ -353,6 +353,21 @@ def test_run_benchmarks_driver(gpu, tmp_path):
         run_benchmarks.run(f, sizes=(2,), num_simulations=1, samples=1)
 
 
+def test_benchmark_solvers_driver(gpu, tmp_path):
+    """BenchmarkSolvers.jl counterpart: every plugin pair over a size sweep, min / max / median time per (size, plugin)."""
+    import csv
+    from quadraticprogramsolver_amd import benchmark_solvers as bs
+    assert bs.GenerateElementsVector(200, 1200, 5) == [200, 450, 700, 950, 1200]        # BenchmarkSolvers.jl:20-25,64
+    assert bs.GenerateElementsVector(10, 1000, 3, logSpace=True) == [10, 100, 1000]
+    f = str(tmp_path / "solvers.csv")
+    vN, tR, rows = bs.run(20, 60, 0, 0, numDims=2, samples=2, csv_path=f)
+    assert vN == [20, 60] and tR.shape == (2, 3, 5) and len(rows) == 6
+    assert np.all(tR[:, :, 0] <= tR[:, :, 2]) and np.all(tR[:, :, 2] <= tR[:, :, 1]) and np.all(tR[:, :, 0] > 0)   # min <= median <= max
+    assert np.all(tR[:, 0, 3] > 0)
+    table = list(csv.reader(open(f)))
+    assert len(table) == 7 and table[0][0] == "Solver"
+
+
 def test_large_n_falls_back_to_unfused_kernels(gpu):
     """n beyond the register-tile limit of the fused kernels (NP > 8192 in fp64): unfused loop, three sweep blocks with a
     ragged last one.  Checked through size-independent properties (linear-solve residual, reported residuals)."""
