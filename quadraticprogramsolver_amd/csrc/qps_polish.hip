@@ -209,7 +209,8 @@ template <typename T> void polish_mask_rows(hipStream_t st, int MP, const T* mas
 template <typename T>
 void polish_dense(hipStream_t st, int64_t n, int64_t m, int NP, int MP, const T* P, const T* A, const T* q, const T* l, const T* u, const T* y,
                   T* x, T* part, const qps_params& p, PolishReport* rep) {
-    const bool fusedA = MP > 0 && apass_proxqp_slabs<T>(NP, MP) > 0;
+    const char* unf = getenv("QPS_POLISH_UNFUSED");                               // 1: force the two-GEMV product (the path of shapes the pass kernel does not cover)
+    const bool fusedA = MP > 0 && apass_proxqp_slabs<T>(NP, MP) > 0 && !(unf && atoi(unf) != 0);
     // out = K v + delta blkdiag(I, -I) v  with the multiplier block masked                         :304-305
     PolishProduct<T> kmat = [&](const T* v, T delta, T* out, const T* mask, T* scratch) {
         gemv_rows<T>(st, P, NP, v, out, v, T(1), delta, 0, NP, 0, NP, 0);                           // P v_x + delta v_x

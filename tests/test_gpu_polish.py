@@ -127,6 +127,24 @@ def test_polish_on_csr_handles_matches_restatement(gpu, np_oracle, pol, monkeypa
     assert i1["polishFlag"] in (0, 1) and i1["polishIterations"] > 0
 
 
+@pytest.mark.parametrize("dtype,unfused", [("f64", "1"), ("f32", "0"), ("f32", "1")])
+def test_polish_other_product_paths(gpu, np_oracle, pol, monkeypatch, dtype, unfused):
+    """The two-GEMV product (used for shapes the fused pass does not cover; forced here) and the fp32 kernels.  fp32 cannot reach the
+    reference's 1e-6 relative MINRES tolerance reliably, so there the test is: a looser tolerance converges and lands on the fp64 answer."""
+    monkeypatch.setenv("QPS_POLISH_UNFUSED", unfused)
+    n, m = 64, 128
+    P, q, A, l, u = problem(n, m, 2)
+    x, y = admm_state(np_oracle, P, q, A, l, u)
+    y = np.where(np.abs(y) > 1e-7, y, 0.0)
+    tol = 1e-9 if dtype == "f64" else 1e-3
+    xr, fr, ir = pol.Polish(P, q, A, l, u, x, y, 10, 1e-6, 1e-9, 4000)
+    with gpu.QuadraticProgram(P, q, A, l, u, dtype=dtype) as prob:
+        xg = x.copy()
+        rep = prob.polish(xg, y, numItrPolish=10, δ=1e-6, ϵMinres=tol, numItrMinres=4000)
+    assert rep["flag"] == 0 and rep["numActiveLower"] == ir["numActiveLower"] and rep["numActiveUpper"] == ir["numActiveUpper"]
+    assert np.abs(xg - xr).max() <= (1e-7 if dtype == "f64" else 5e-3) * max(1.0, np.abs(xr).max())
+
+
 def test_polish_without_constraints_is_the_unconstrained_minimiser(gpu):
     n = 96
     P, q, _, _, _ = problem(n, 8, 7)

@@ -72,3 +72,34 @@ def test_demo_run_converges_to_the_constrained_optimum(gpu, po):
         assert rg["Converged"] and rr["Converged"]
         assert np.abs(prob.vX - ref.vX).max() <= 1e-7
         assert np.abs(A @ prob.vX - b).max() <= 1e-6 and np.maximum(C @ prob.vX - d, 0).max() <= 1e-6
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fp32_handles_track_the_fp64_restatement(gpu, po, variant):
+    """dtype="f32": same kernels with T = float; after 100 iterations the state agrees with the fp64 restatement to fp32 accuracy."""
+    P, q, A, b, C, d = make_problem(120, 40, 100, 5)
+    ref = po.ProxQP.from_problem(P, q, A, b, C, d)
+    init = po.ProxQP.from_problem(P, q, A, b, C, d)
+    po.SolveQuadraticProgramProxQP(ref, numIterations=100, ρ=50.0, σ=1e-2, adptΡ=False)
+    with gpu.ProxQP(P, q, A, b, C, d, init.vX, init.vY, init.vZ, init.vS, dtype="f32") as prob:
+        gpu.SolveQuadraticProgramProxQP(prob, numIterations=100, ρ=50.0, σ=1e-2, adptΡ=False, loopVariant=variant)
+        assert rel(prob.vX, ref.vX) <= 2e-3 and rel(prob.vS, ref.vS) <= 2e-3
+        assert rel(prob.vY, ref.vY) <= 2e-2 and rel(prob.vZ, ref.vZ) <= 2e-2
+
+
+def test_error_behaviour(gpu):
+    P, q, A, b, C, d = make_problem(40, 10, 30, 2)
+    with pytest.raises(ValueError):
+        gpu.ProxQP(P, q, A[:, :-1], b, C, d)                                   # dimension mismatch is caught before the device is touched
+    with pytest.raises(ValueError):
+        gpu.ProxQP(P, q[:-1], A, b, C, d)
+    Pbad = P.copy(); Pbad[3, 3] = -50.0                                        # not positive definite: the KKT initialisation factorises P
+    with pytest.raises(gpu.QpsError) as e:
+        gpu.ProxQP(Pbad, q, A, b, C, d)
+    assert e.value.status == 4 and "pivot" in e.value.message
+    # a rank-deficient equality block makes A P^-1 A' singular; like the reference's `mK \\ vK` (ProxQP.jl:81) that is only an error when
+    # a pivot is exactly non-positive, so it is not asserted here; with an explicit state no KKT solve is needed at all
+    A2 = np.vstack([A, A[:1]]); b2 = np.concatenate([b, b[:1]])
+    with gpu.ProxQP(P, q, A2, b2, C, d, np.zeros(40), np.zeros(11), np.zeros(30), np.zeros(30)) as prob:   # explicit state: no KKT solve needed
+        rep = gpu.SolveQuadraticProgramProxQP(prob, numIterations=200)
+        assert np.isfinite(rep["PrimalResidual"])
