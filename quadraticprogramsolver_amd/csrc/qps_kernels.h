@@ -8,6 +8,9 @@
 //         sweeps are then row-dot-product GEMVs over S (forward reads c <= r, backward reads c >= r).
 //   vectors of length n / m are allocated NP / MP long and zero padded.
 #pragma once
+#ifndef QPS_NT_SLABS
+#define QPS_NT_SLABS 1   // non-temporal (write-through) stores for the per-workgroup slabs of the pass and sweep kernels
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
