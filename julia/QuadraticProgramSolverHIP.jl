@@ -153,3 +153,54 @@ function SolveQuadraticProgram!(sQpProb :: ProxQPHip{Float64}; numIterations = 2
     return Dict{String, Real}("Converged" => rep.converged != 0, "Iterations" => rep.iterations, "ρ" => rep.rho, "σ" => rep.sigma,
                               "PrimalResidual" => rep.resPrim, "DualResidual" => rep.resDual)     # ProxQP.jl:127
 end
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Polishing step of the MATLAB implementation (SolveQuadraticProgram.m:289-325) on the device: `polish = true` in
+# `SolveQuadraticProgram!` chains it after the loop; `PolishQuadraticProgram!` runs it alone on a given (vX, vY).
+# ---------------------------------------------------------------------------------------------------------------------
+mutable struct QpsPolishReport
+    flag::Int32; refinements::Int32; minresIterations::Int32; numActiveLower::Int32; numActiveUpper::Int32; reserved0::Int32
+    relres::Float64; seconds::Float64
+    QpsPolishReport() = new(-1, 0, 0, 0, 0, 0, NaN, 0.0)
+end
+function PolishQuadraticProgram!(vX::Vector{Float64}, vY::Vector{Float64}, mP, vQ, mA, vL, vU;
+    numItrPolish = 10, δ = 1e-6, ϵMinres = 1e-6, numItrMinres = 500, densePath::Bool = true)
+    h = _create(mP, Vector{Float64}(vQ), mA, Vector{Float64}(vL), Vector{Float64}(vU); densePath = densePath)
+    try
+        prm = QpsParams(5000, false, 25, numItrPolish, numItrMinres, densePath ? 1 : 2, 0, 0,
+                        1e-6, 1e-6, 1.0, 1e-6, 1.6, δ, 5.0, ϵMinres, 1e-6, 1000, 0, 1, 0)
+        rep = QpsPolishReport()
+        GC.@preserve vX vY _check(ccall((:qps_polish, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{QpsParams}, Ref{QpsPolishReport}),
+                                        h, vX, vY, Ref(prm), rep), h)
+        return rep          # rep.flag == 0: vX was replaced by the polished primal (minresFlag semantics of :311-325)
+    finally
+        ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), h)
+    end
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A batch of independent dense QPs of one shape (the per-problem loop of RunBenchmarks.jl:88-104 advanced in lock step).
+# mX is n x count (one column per problem: warm starts in, solutions out).
+# ---------------------------------------------------------------------------------------------------------------------
+function SolveQuadraticProgramBatch!(mX::Matrix{Float64}, vmP::Vector{Matrix{Float64}}, mQ::Matrix{Float64}, vmA::Vector{Matrix{Float64}},
+    mL::Matrix{Float64}, mU::Matrix{Float64}; numIterations = 5000, ϵAbs = 1e-6, ϵRel = 1e-6, ρ = 1, σ = 1e-6, α = 1.6,
+    adptΡ::Bool = false, fctrΡ = 5, numItrConv = 25, device = 0)
+    count = length(vmP); n = size(vmP[1], 1); m = size(vmA[1], 1)
+    P = reduce(hcat, vec.(vmP)); A = m > 0 ? reduce(hcat, vec.(vmA)) : zeros(1, count)     # column-major matrices back to back
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve P A mQ mL mU _check(ccall((:qps_create_dense_batch, LIBQPS), Int32,
+        (Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ref{Ptr{Cvoid}}),
+        count, n, m, P, A, mQ, mL, mU, Int32(0), Int32(device), h))
+    try
+        prm = QpsParams(numIterations, adptΡ, numItrConv, 10, 500, 0, 0, 0, ϵAbs, ϵRel, ρ, σ, α, 1e-6, fctrΡ, 1e-6, 1e-6, 1000, 0, 0, 0)
+        infos = [QpsInfo() for _ in 1:count]
+        buf = Vector{UInt8}(undef, count * sizeof(QpsInfo))
+        GC.@preserve mX buf _check(ccall((:qps_solve_batch, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{QpsParams}, Ptr{UInt8}),
+                                         h[], mX, Ref(prm), buf), h[])
+        flags = [ConvergenceFlag(unsafe_load(Ptr{Int32}(pointer(buf) + (b - 1) * sizeof(QpsInfo)))) for b in 1:count]
+        return flags
+    finally
+        ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), h[])
+    end
+end

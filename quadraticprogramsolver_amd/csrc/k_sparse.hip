@@ -347,18 +347,11 @@ __global__ __launch_bounds__(256) void k_axpby(int n, T a, const T* __restrict__
 }
 
 struct Csr {
-    int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int lpr = 16; int* rb = nullptr; int nblocks = 0;
+    int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int* rb = nullptr; int nblocks = 0;
     // column-blocked copy (k_spmv_blk): nblk CSR blocks back to back; used when `blocked`
     bool blocked = false; int ncols = 0, nblk = 0, wpb = 0; int* brp = nullptr; unsigned short* bci = nullptr; void* bva = nullptr;
     int* task_ptr = nullptr; int4* tasks = nullptr; int per = 1, lpr4 = 0; void* partial = nullptr;
 };
-
-int pick_lpr(int64_t nnz, int nrows) {
-    const double avg = nrows > 0 ? (double)nnz / nrows : 0.0;
-    int l = 4;
-    while (l < 64 && l * 4 < avg) l *= 2;   // about 4 non-zeros per lane
-    return l;
-}
 
 template <typename T> struct SparseSolver : SolverBase {
     Csr A, At, P, PA;   // PA = [P; A] stacked, column-blocked only: P u and A u of the CG operator from ONE pass over u
@@ -426,7 +419,7 @@ template <typename T> struct SparseSolver : SolverBase {
         M.blocked = true;
     }
     void upload_csr(Csr& M, int nrows, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
-        M.nrows = nrows; M.nnz = (int64_t)ci.size(); M.lpr = pick_lpr(M.nnz, nrows);
+        M.nrows = nrows; M.nnz = (int64_t)ci.size();
         {   // LDS-resident x pays once the gathers dominate; QPS_SPMV_BLOCKED = 1 / 0 forces the choice
             const char* e = getenv("QPS_SPMV_BLOCKED");
             const bool want = e ? atoi(e) != 0 : M.nnz >= 200000;
