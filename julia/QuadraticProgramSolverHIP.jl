@@ -194,7 +194,6 @@ function SolveQuadraticProgramBatch!(mX::Matrix{Float64}, vmP::Vector{Matrix{Flo
         count, n, m, P, A, mQ, mL, mU, Int32(0), Int32(device), h))
     try
         prm = QpsParams(numIterations, adptΡ, numItrConv, 10, 500, 0, 0, 0, ϵAbs, ϵRel, ρ, σ, α, 1e-6, fctrΡ, 1e-6, 1e-6, 1000, 0, 0, 0)
-        infos = [QpsInfo() for _ in 1:count]
         buf = Vector{UInt8}(undef, count * sizeof(QpsInfo))
         GC.@preserve mX buf _check(ccall((:qps_solve_batch, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{QpsParams}, Ptr{UInt8}),
                                          h[], mX, Ref(prm), buf), h[])
