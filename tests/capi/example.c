@@ -44,6 +44,38 @@ int main(void) {
     }
     printf("plugin pair residual=%.3e\n", res);
     ok = ok && res <= 1e-12;
+    /* polishing step alone (SolveQuadraticProgram.m:289-325): multiplier signs of the known answer -> exact KKT point */
+    {
+        double yk[N], xp[N]; qps_polish_report prep;
+        for (int i = 0; i < N; ++i) {                                          /* y = -(P x* + q) on clamped rows, 0 elsewhere (A = I) */
+            const double g = P[i + i * N] * xstar[i] + q[i];
+            yk[i] = (xstar[i] == u[i] || xstar[i] == l[i]) ? -g : 0.0; xp[i] = x[i];
+        }
+        qps_params pp; qps_default_params(&pp); pp.epsMinres = 1e-12; pp.numItrMinres = 200;
+        rc = qps_polish(h, xp, yk, &pp, &prep);
+        if (rc != QPS_OK) { fprintf(stderr, "polish failed: %s\n", qps_last_error(h)); return 1; }
+        double dp = 0.0;
+        for (int i = 0; i < N; ++i) dp = fmax(dp, fabs(xp[i] - xstar[i]));
+        printf("polish flag=%d active=%d+%d minres=%d max|x-x*|=%.3e\n", prep.flag, prep.numActiveLower, prep.numActiveUpper, prep.minresIterations, dp);
+        ok = ok && prep.flag == 0 && dp <= 1e-6;   /* delta = 1e-6 regularisation, ten refinement steps */
+    }
+    /* second solver form (ProxQP.jl): min 1/2 x'Px + q'x  s.t.  x_0 + x_1 = 1 (A x = b),  x <= 0.5 (C x <= d) */
+    {
+        double Aeq[N] = {1.0, 1.0, 0, 0, 0, 0}, beq[1] = {1.0}, dd[N], xs[N], ys[1], zs[N], ss[N];
+        for (int i = 0; i < N; ++i) dd[i] = 0.5;
+        qps_handle hp = NULL; qps_proxqp_params qp; qps_proxqp_report qr;
+        rc = qps_proxqp_create_dense(N, 1, N, P, N, q, Aeq, 1, beq, A, N, dd, QPS_F64, 0, &hp);
+        if (rc == QPS_OK) rc = qps_proxqp_init_kkt(hp);
+        qps_proxqp_default_params(&qp); qp.numIterations = 3000;
+        if (rc == QPS_OK) rc = qps_proxqp_solve(hp, &qp, &qr);
+        if (rc == QPS_OK) rc = qps_proxqp_get_state(hp, xs, ys, zs, ss);
+        if (rc != QPS_OK) { fprintf(stderr, "proxqp failed: %s\n", qps_last_error(hp)); return 1; }
+        double viol = fabs(xs[0] + xs[1] - 1.0);
+        for (int i = 0; i < N; ++i) viol = fmax(viol, xs[i] - 0.5);
+        printf("proxqp converged=%d iterations=%d violation=%.3e\n", qr.converged, qr.iterations, viol);
+        ok = ok && qr.converged && viol <= 1e-5;
+        qps_destroy(hp);
+    }
     /* error path: a non-positive-definite problem must be reported, not hidden */
     qps_handle hb = NULL;
     for (int i = 0; i < N; ++i) P[i + i * N] = -1.0;
