@@ -169,8 +169,9 @@ int32_t qps_solve_batch(qps_handle h, double *x_inout, const qps_params *params,
  * (used by bench.py's roofline block).  names is a caller buffer of `cap` entries; returns the number filled. */
 typedef struct { char name[48]; double seconds; int64_t launches; double algo_bytes; } qps_kernel_time;
 int32_t qps_kernel_times(qps_handle h, qps_kernel_time *out, int32_t cap, int32_t *count);
-/* level 0 = off; 1 = bracket the dominant loop kernel with HIP events on every 50th iteration (cheap enough for a timed
- * region: an event pair per launch would cost ~7 % of the loop);
+/* level 0 = off; 1 = sampling: once per 50 iterations ONE launch of each loop kernel (fused pass, fused sweeps, the two slab
+ * reductions; each on a different iteration) is bracketed with HIP events -- cheap enough for a timed region (an event pair
+ * per launch would cost ~7 % of the loop);
  * 2 = bracket every loop kernel (diagnostic).  Setting the level also resets the accumulated times. */
 int32_t qps_set_profiling(qps_handle h, int32_t on);
 

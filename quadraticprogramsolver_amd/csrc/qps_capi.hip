@@ -36,6 +36,8 @@ template <typename T> struct DenseSolver : SolverBase {
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
     int nb = 2048; int part_tiles = 0; int num_factorizations = 0;
+    int prof_iter = 0;   // iteration index seen by the level-1 sampler (one bracketed launch per kernel kind per 50 iterations)
+    int sample_lvl(int slot) const { return (prof.level == 1 && prof_iter % 50 == slot) ? 1 : 2; }
     int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk, cat_sweep, cat_xsum;
 
     DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
@@ -153,8 +155,8 @@ template <typename T> struct DenseSolver : SolverBase {
         if (nblk == 1 && sweep_mode == 2 && sweep_fused_supported<T>(NP)) {
             // one inverted block: forward and backward sweep read the same entries -> one fused pass over the triangle
             int G;
-            { ProfScope ps(prof, cat_sweep, 2); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
-            { ProfScope ps(prof, cat_xsum, 2); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
+            { ProfScope ps(prof, cat_sweep, sample_lvl(13)); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
+            { ProfScope ps(prof, cat_xsum, sample_lvl(21)); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
             return;
         }
         {
@@ -276,8 +278,9 @@ template <typename T> struct DenseSolver : SolverBase {
                     ProfScope ps(prof, cat_atw, 2);
                     rhs_slabs = gemv_cols_partial<T>(st, A, NP, z, y, (T)rho, T(-1), part, NP, MP, NP);
                 }
+                prof_iter = ii;
                 {
-                    ProfScope ps(prof, cat_colsum, 2);
+                    ProfScope ps(prof, cat_colsum, sample_lvl(29));
                     colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP);              // LinearSystemSolvers.jl:136
                 }
                 sweeps();                                                                           // :137
