@@ -282,38 +282,52 @@ __global__ __launch_bounds__(256) void k_inv64(const T* __restrict__ L, int64_t 
     for (int jj = 0; jj < 16; ++jj) dinv[(int64_t)kb * 4096 + i * 64 + 16 * g + jj] = x[jj];
 }
 
-// Panel solve X * L11' = A21 (in place), one thread per row of A21: x_j = (a_j - sum_{k<j} x_k L11[j][k]) / L11[j][j].
-// L11 sits in LDS and every lane reads the same element at the same time (broadcast).
+template <typename T, int J> struct TrsmStep {
+    // one column of the substitution for a row owned by 4 lanes (lane part p holds x_k for k = p mod 4): partial sums over the
+    // lane's k < J, two DPP-class shuffles, scale; everything indexed at compile time
+    static __device__ __forceinline__ void run(T (&xs)[16], const T (*Ls)[65], const T* rdiag, T (*Xs)[65], int r, int p) {
+        T s = (p == (J & 3)) ? Xs[r][J] : T(0);
+#pragma unroll
+        for (int i = 0; i < (J + 3) / 4; ++i) {
+            const int k = 4 * i + p;
+            if (k < J) s -= xs[i] * Ls[J][k];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        const T xj = s * rdiag[J];
+        if (p == (J & 3)) { xs[J >> 2] = xj; Xs[r][J] = xj; }
+        TrsmStep<T, J + 1>::run(xs, Ls, rdiag, Xs, r, p);
+    }
+};
+template <typename T> struct TrsmStep<T, 64> { static __device__ __forceinline__ void run(T (&)[16], const T (*)[65], const T*, T (*)[65], int, int) {} };
+
+// Panel solve X * L11' = A21 (in place) for one 64 x 64 tile of A21 per workgroup.  256 threads: the two tiles travel through
+// LDS with lanes along a row (one 512-B segment per load instruction, four row groups in parallel); then 4 lanes share a row
+// of the substitution  x_j = (a_j - sum_{k<j} x_k L11[j][k]) / L11[j][j].
 template <typename T>
-__global__ __launch_bounds__(64) void k_trsm_panel(T* __restrict__ M, int64_t ld, int kb, int nrows, int64_t sM) {
+__global__ __launch_bounds__(256) void k_trsm_panel(T* __restrict__ M, int64_t ld, int kb, int nrows, int64_t sM) {
     __shared__ T Ls[64][65];
     __shared__ T Xs[64][65];
     __shared__ T rdiag[64];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, c = t & 63, g = t >> 6;
     M += (int64_t)blockIdx.y * sM;
     const T* L11 = M + (int64_t)kb * 64 * ld + kb * 64;
-    T* a0 = M + (int64_t)((kb + 1) * 64 + blockIdx.x * 64) * ld + kb * 64;      // this workgroup's 64 x 64 tile of A21 (nrows is a multiple of 64)
-    // both tiles through LDS with lanes along a row (one 512-B segment per load instruction); a thread then owns one row
-#pragma unroll 16
-    for (int r = 0; r < 64; ++r) { Ls[r][t] = L11[(int64_t)r * ld + t]; Xs[r][t] = a0[(int64_t)r * ld + t]; }
+    T* a0 = M + (int64_t)((kb + 1) * 64 + blockIdx.x * 64) * ld + kb * 64;      // this workgroup's tile of A21 (nrows is a multiple of 64)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int r = g + 4 * i; Ls[r][c] = L11[(int64_t)r * ld + c]; Xs[r][c] = a0[(int64_t)r * ld + c]; }
     __syncthreads();
-    rdiag[t] = T(1) / Ls[t][t];
+    if (t < 64) rdiag[t] = T(1) / Ls[t][t];
     __syncthreads();
-    T x[64];
+    {
+        const int r = t >> 2, p = t & 3;
+        T xs[16];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) x[j] = Xs[t][j];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        T s = x[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s -= x[k] * Ls[j][k];
-        x[j] = s * rdiag[j];
+        for (int i = 0; i < 16; ++i) xs[i] = T(0);
+        TrsmStep<T, 0>::run(xs, Ls, rdiag, Xs, r, p);
     }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) Xs[t][j] = x[j];
     __syncthreads();
-#pragma unroll 16
-    for (int r = 0; r < 64; ++r) a0[(int64_t)r * ld + t] = Xs[r][t];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int r = g + 4 * i; a0[(int64_t)r * ld + c] = Xs[r][c]; }
     (void)nrows;
 }
 
@@ -382,7 +396,7 @@ template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* 
         const int rem = NP - (kb + 1) * 64;
         if (rem <= 0) break;
         // L21 = A21 * inv(L11)'  by forward substitution, one thread per row
-        hipLaunchKernelGGL((k_trsm_panel<T>), dim3(rem / 64, batch), dim3(64), 0, st, M, (int64_t)NP, kb, rem, sM);
+        hipLaunchKernelGGL((k_trsm_panel<T>), dim3(rem / 64, batch), dim3(256), 0, st, M, (int64_t)NP, kb, rem, sM);
         // A22 -= L21 * L21'  (lower tiles only) + factorisation of diagonal block kb + 1
         hipLaunchKernelGGL((k_update_potrf<T>), dim3(rem / 64, rem / 64, batch), dim3(256), 0, st, M, (int64_t)NP, kb, fail_dev, sM);
     }
