@@ -10,6 +10,9 @@
  *   LinSysSolInit(vX,mP,vQ,mA,rho,rho1,sigma,n,m)     LinearSystemSolvers.jl:16,47,78,110,145 -> qps_linsys_init
  *   LinSysSol!(tuSolver,vXX,vZZ,vX,...,changedRho)    LinearSystemSolvers.jl:28,59,91,125,164 -> qps_linsys_solve
  *   @enum ConvergenceFlag                             SolveQuadraticProgram.jl:12      -> qps_conv_flag
+ *   polishing block (MATLAB implementation only)      SolveQuadraticProgram.m:289-325  -> qps_polish, qps_params.polish
+ *   ProxQP(mP,vQ,mA,vB,mC,vD[,vX,vY,vZ,vS]) + SolveQuadraticProgram!(sQpProb; kw...) -> dReport
+ *                                                     ProxQP.jl:36,73-93,118-173      -> qps_proxqp_*
  *
  * Everything crossing this boundary is a plain pointer, size or scalar.  Host arrays stay owned by the caller and may
  * be freed as soon as the call that received them returns (qps_create_* copies the problem into HBM).
@@ -56,7 +59,8 @@ typedef enum {
 } qps_linsys_kind;
 
 /* Keyword arguments of SolveQuadraticProgram! (SolveQuadraticProgram.jl:15-17), same names, same defaults.
- * delta, numItrPolish, epsMinres, numItrMinres are accepted and ignored exactly as the reference does. */
+ * delta, numItrPolish, epsMinres, numItrMinres are accepted and, exactly as in the reference, unused by the loop; they drive the
+ * polishing step of the MATLAB implementation when `polish` is set (see qps_polish below). */
 typedef struct {
     int32_t numIterations;   /* 5000 */
     int32_t adptRho;         /* adptΡ, 0/1, default 0 */
