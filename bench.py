@@ -219,7 +219,7 @@ def pmc_traffic(kernel_label, dtype):
     try:
         d = json.load(open(path))
         for name, v in d.items():
-            if name.startswith("k_apass<double") and name.endswith("false>"):
+            if name.startswith("k_apass<double") and (name.endswith("false>") or name.endswith("false, 0>")):   # the plain ADMM variant
                 return v["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
     except Exception:
         pass
