@@ -51,16 +51,30 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
     // (opA(i,k) = 0 for k > i) -> stop after the diagonal tile of row block i0
     const int kbeg = (ktri == 1) ? j0 : 0;
     const int kend = (ktri == 2) ? min(K, i0 + GT) : K;
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // stage opA(i0.., k0..) as As[k][i] and opB(k0.., j0..) as Bs[k][j]; 4 elements per thread each
+    // opA(i0.., k0..) goes to As[k][i], opB(k0.., j0..) to Bs[k][j], 4 elements per thread each; the slab of the NEXT k-step is
+    // fetched into registers before the MFMAs of the current one (the global-load latency overlaps the multiply instead of
+    // relying on other workgroups of the CU to cover it)
+    T ga[4], gb[4];
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[k][i] = A[(int64_t)(i0 + i) * lda + k0 + k]; }
-            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[k][i] = A[(int64_t)(k0 + k) * lda + i0 + i]; }
-            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[k][j] = B[(int64_t)(j0 + j) * ldb + k0 + k]; }
-            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[k][j] = B[(int64_t)(k0 + k) * ldb + j0 + j]; }
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; ga[r] = A[(int64_t)(i0 + i) * lda + k0 + k]; }
+            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  ga[r] = A[(int64_t)(k0 + k) * lda + i0 + i]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; gb[r] = B[(int64_t)(j0 + j) * ldb + k0 + k]; }
+            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  gb[r] = B[(int64_t)(k0 + k) * ldb + j0 + j]; }
+        }
+    };
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[k][i] = ga[r]; }
+            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[k][i] = ga[r]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[k][j] = gb[r]; }
+            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[k][j] = gb[r]; }
         }
         __syncthreads();
+        if (k0 + GK < kend) gload(k0 + GK);
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4), cl = lane & 15;
