@@ -33,9 +33,9 @@ constexpr int GLD = 80;   // LDS row stride (elements): k-groups of a fragment r
 // tile != nullptr: the finished C tile goes to that LDS array (row stride 65) INSTEAD of global memory
 template <typename T, bool AK, bool BK>
 __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, T beta,
-                                          T* __restrict__ C, int64_t ldc, int ktri, int bi, int bj, T (*tile)[65]) {
-    __shared__ T As[GK][GLD];
-    __shared__ T Bs[GK][GLD];
+                                          T* __restrict__ C, int64_t ldc, int ktri, int bi, int bj, T (*As)[GK][GLD], T (*Bs)[GK][GLD],
+                                          T (*tile)[65]) {
+    // As, Bs: the caller's double-buffered LDS staging arrays [2][GK][GLD] (one barrier per k-step); `tile` may alias them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     using acc_t = typename Mfma<T>::acc_t;
@@ -65,28 +65,29 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
         }
     };
     if (kbeg < kend) gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[k][i] = ga[r]; }
-            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[k][i] = ga[r]; }
-            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[k][j] = gb[r]; }
-            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[k][j] = gb[r]; }
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[buf][k][i] = ga[r]; }
+            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[buf][k][i] = ga[r]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[buf][k][j] = gb[r]; }
+            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[buf][k][j] = gb[r]; }
         }
-        __syncthreads();
+        __syncthreads();   // also orders this step's reads of `buf` after the stores above, and the stores of step k+2 into `buf` after them
         if (k0 + GK < kend) gload(k0 + GK);
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4), cl = lane & 15;
-            const T a0 = As[kr][wm * 32 + cl], a1 = As[kr][wm * 32 + 16 + cl];
-            const T b0 = Bs[kr][wn * 32 + cl], b1 = Bs[kr][wn * 32 + 16 + cl];
+            const T a0 = As[buf][kr][wm * 32 + cl], a1 = As[buf][kr][wm * 32 + 16 + cl];
+            const T b0 = Bs[buf][kr][wn * 32 + cl], b1 = Bs[buf][kr][wn * 32 + 16 + cl];
             acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
             acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
             acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
             acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
         }
-        __syncthreads();
     }
+    if (tile) __syncthreads();   // the tile may live in the staging buffers: every wave must be done reading them
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -109,7 +110,9 @@ __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restric
     const int bj = blockIdx.x, bi = blockIdx.y;
     if (lower_only && bj > bi) return;
     A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
-    gemm_tile<T, AK, BK>(K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bi, bj, nullptr);
+    __shared__ T As[2][GK][GLD];
+    __shared__ T Bs[2][GK][GLD];
+    gemm_tile<T, AK, BK>(K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bi, bj, As, Bs, nullptr);
 }
 
 // column-major double src (rows x cols) -> row-major T dst (ld ldd), via a 64 x 64 LDS transpose tile; dst padding is
@@ -250,11 +253,13 @@ __global__ __launch_bounds__(256) void k_update_potrf(T* __restrict__ M, int64_t
     const int bj = blockIdx.x, bi = blockIdx.y;
     if (bj > bi) return;
     M += (int64_t)blockIdx.z * sM; fail += blockIdx.z;
-    __shared__ T tile[64][65];
+    __shared__ T stage[2][2][GK][GLD];                                            // As | Bs; reused as the 64 x 65 tile of the (0, 0) workgroup
+    static_assert(sizeof(T) * 64 * 65 <= sizeof(T) * 2 * 2 * GK * GLD, "tile must fit into the staging buffers");
+    T (*tile)[65] = reinterpret_cast<T (*)[65]>(&stage[0][0][0][0]);
     const T* A21 = M + (int64_t)(kb + 1) * 64 * ld + kb * 64;
     T* A22 = M + (int64_t)(kb + 1) * 64 * ld + (kb + 1) * 64;
     const bool diag0 = (bi == 0 && bj == 0);                                      // workgroup-uniform
-    gemm_tile<T, true, true>(64, T(-1), A21, ld, A21, ld, T(1), A22, ld, 0, bi, bj, diag0 ? tile : nullptr);
+    gemm_tile<T, true, true>(64, T(-1), A21, ld, A21, ld, T(1), A22, ld, 0, bi, bj, stage[0], stage[1], diag0 ? tile : nullptr);
     if (diag0) {
         __syncthreads();
         potrf_block<T>(A22, ld, kb + 1, fail, tile);
