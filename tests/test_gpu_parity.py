@@ -473,3 +473,48 @@ def test_concurrent_handles_from_two_host_threads(gpu, c_oracle):
         xo, io = c_oracle.solve(*cases[k], numIterations=50000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
         for x, flag, its in results[k]:
             assert flag == io["convFlag"] and its == io["iterations"] and np.abs(x - xo).max() <= ABS_DEV_THR
+
+
+KNOBS = [{"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
+         {"QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"}]
+
+
+@pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_tuning_knobs_do_not_change_results(gpu, knob, tmp_path):
+    """Every QPS_* environment knob only selects a launch geometry / kernel variant: a child process with the knob set must
+    reproduce the iterates of the default configuration (the knobs are read once per process, hence the subprocess)."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent('''
+        import sys, json, numpy as np
+        sys.path.insert(0, sys.argv[1])
+        import quadraticprogramsolver_amd as q
+        out = {}
+        for tag, (n, m) in {"small": (64, 128), "mid": (1100, 2300)}.items():
+            P, qq, A, l, u = q.GenerateDenseBenchmarkQP(n, m, stream=7, feasible=True)
+            x = np.zeros(n); q.SolveQuadraticProgramInplace(x, P, qq, A, l, u, numIterations=60, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
+            out[tag] = x.tolist()
+        Ps, qs, As, ls, us = q.GenerateSparseBenchmarkQP(3000, 5000, densityA=4e-3, seed=5)
+        x = np.zeros(3000)
+        with q.QuadraticProgram(Ps, qs, As, ls, us, linsys="cg") as prob:
+            prob.solve(x, numIterations=15, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, ϵPcg=1e-12, numItrPcg=3000)
+        out["cg"] = x.tolist()
+        print(json.dumps(out))
+    ''')
+    f = tmp_path / "knob.py"; f.write_text(script)
+
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("QPS_")}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, str(f), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return {k: np.array(v) for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+
+    global _KNOB_BASE
+    try:
+        base = _KNOB_BASE
+    except NameError:
+        base = _KNOB_BASE = run({})
+    got = run(knob)
+    for tag in base:
+        assert np.abs(got[tag] - base[tag]).max() <= 1e-9 * max(1.0, np.abs(base[tag]).max()), (knob, tag)
