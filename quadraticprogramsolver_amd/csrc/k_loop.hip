@@ -3,16 +3,13 @@
 #include <cstdlib>
 
 #include "qps_kernels.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
 namespace {
 
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) { return wave_sum_all(v); }   // DPP + readlane (wave_reduce.h)
 // NaN-propagating max of non-negative values via their bit pattern (IEEE: for x >= 0 the unsigned order of the bits
 // is the numeric order, and a positive NaN sorts above +Inf), matching Julia's norm(v, Inf) / max.
 __device__ __forceinline__ unsigned long long absbits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }

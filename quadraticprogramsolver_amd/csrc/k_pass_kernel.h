@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "qps_kernels.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
 #pragma unroll
                 for (int e = 0; e < VN; ++e) { s += ap[e] * xp_[e]; if (CHECK) s2 += ap[e] * xq_[e]; }
             }
-            d[i] = wsum(s);
-            if (CHECK) d2[i] = wsum(s2);
+            d[i] = wave_sum_all(s);                       // DPP + readlane, no LDS-pipe instruction (wave_reduce.h)
+            if (CHECK) d2[i] = wave_sum_all(s2);
         }
         if ((tid & 63) == 0) {
 #pragma unroll

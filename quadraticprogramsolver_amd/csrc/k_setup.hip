@@ -3,6 +3,7 @@
 // Reference: LinearSystemSolvers.jl:112-114 (mAA, mPI, mL), :127-129 (rebuild on changedRho), ProxQP.jl:175-206
 // (dense Cholesky + in-place re-factorisation precedent).
 #include "qps_kernels.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
@@ -311,8 +312,7 @@ template <typename T, int J> struct TrsmStep {
             const int k = 4 * i + p;
             if (k < J) s -= xs[i] * Ls[J][k];
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
+        s = quad_sum_all(s);                                 // DPP quad_perm: no LDS round trip inside the 64-step chain
         const T xj = s * rdiag[J];
         if (p == (J & 3)) { xs[J >> 2] = xj; Xs[r][J] = xj; }
         TrsmStep<T, J + 1>::run(xs, Ls, rdiag, Xs, r, p);

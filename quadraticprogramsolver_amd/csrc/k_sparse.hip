@@ -17,6 +17,7 @@
 #include "qps_internal.h"
 #include "qps_kernels.h"
 #include "qps_polish.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ rb,
             const int s0 = rp[row] - base, s1 = rp[row + 1] - base;
             T s = T(0);
             for (int k = s0 + lane; k < s1; k += 8) s += prod[k];
-            s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+            s = oct_sum_all(s);
             if (lane == 0) {
                 T r = a * s;
                 if (v0) r += b0 * v0[row];
@@ -211,8 +212,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
             const int s0 = rps[i], s1 = rps[i + 1];
             T s = T(0);
             for (int k = s0 + lane; k < s1; k += LPR) s += prod[k];
-            if (LPR == 8) s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+            s = (LPR == 8) ? oct_sum_all(s) : quad_sum_all(s);   // DPP: the LDS pipe is busy with the x gathers
             if (lane == 0) pout[r0 + i] = s;
         }
         __syncthreads();

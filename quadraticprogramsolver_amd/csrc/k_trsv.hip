@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "qps_kernels.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
@@ -75,15 +76,16 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
                     s += ap[e] * xp[e];
                 }
             }
-            s = wsum(s);
+            s = wave_sum_all(s);                                   // DPP + readlane: no LDS-pipe instruction
             if ((tid & 63) == 0) red[par][tid >> 6][i] = s;
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            T y = T(0);
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) y += red[par][w][i];   // fixed order, identical in every thread
+            // lanes 0..WAVES-1 fetch one per-wave partial each (one LDS read per row and wave instead of WAVES broadcast reads per
+            // thread); fixed order, identical in every wave
+            static_assert(WAVES <= 8, "one partial per lane of the first eight");
+            const T y = lanes8_sum_all(((tid & 63) < WAVES) ? red[par][tid & 63][i] : T(0));
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 const T* ap = reinterpret_cast<const T*>(&a[i][k]);
