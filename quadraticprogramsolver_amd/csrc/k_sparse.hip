@@ -27,8 +27,7 @@ struct CgState { double res2, prev2, tol, uc; int iters, done, maxiter, pad; }; 
 constexpr int STREAM_NNZ = 1024;   // non-zeros streamed per workgroup (256 threads x 4)
 
 __device__ __forceinline__ double block_sum_256(double v, double* sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum_all(v);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     const double r = sh[0] + sh[1] + sh[2] + sh[3];
@@ -138,8 +137,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
         if (!fu.first) {
             double d = 0.0;
             for (int i = tid; i < fu.nparts; i += BTHREADS) d += fu.part_rr[i];            // same order in every workgroup
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            d = wave_sum_all(d);
             if ((tid & 63) == 0) sh[tid >> 6] = d;
             __syncthreads();
             d = 0.0;
@@ -193,8 +191,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
             T s = T(0);
             for (int k = base + tid; k < end; k += BTHREADS) s += va[k] * xs[ci[k]];
             double d = (double)s;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            d = wave_sum_all(d);
             if ((tid & 63) == 0) sh[tid >> 6] = d;
             __syncthreads();
             if (tid == 0) { double tot = 0.0; for (int w = 0; w < BTHREADS / 64; ++w) tot += sh[w]; pout[r0] = (T)tot; }

@@ -18,6 +18,7 @@
 #include "qps_internal.h"
 #include "qps_kernels.h"
 #include "qps_polish.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
@@ -26,8 +27,7 @@ namespace {
 struct MrState { double beta, oldb, dbar, epsln, phibar, cs, sn, bnorm, tol, alfa; int itn, done, flag, maxit; };
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum_all(v);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     const double r = sh[0] + sh[1] + sh[2] + sh[3];
