@@ -169,7 +169,8 @@ int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, const double
                                const double *l, const double *u, int32_t dtype, int32_t device, qps_handle *out);
 int32_t qps_solve_batch(qps_handle h, double *x_inout, const qps_params *params, qps_info *infos);
 
-/* Device-time of the dominant loop kernels of the last qps_solve, measured with HIP events on the solver's stream
+/* Device-time of the loop kernels of the last qps_solve, measured with HIP events attached to the kernel dispatches
+ * themselves (hipExtLaunchKernelGGL start / stop events on the solver's stream: the dispatch's own begin / end timestamps)
  * (used by bench.py's roofline block).  names is a caller buffer of `cap` entries; returns the number filled. */
 typedef struct { char name[48]; double seconds; int64_t launches; double algo_bytes; } qps_kernel_time;
 int32_t qps_kernel_times(qps_handle h, qps_kernel_time *out, int32_t cap, int32_t *count);

@@ -17,6 +17,7 @@
 
 #include "qps_kernels.h"
 #include "wave_reduce.h"
+#include <hip/hip_ext.h>
 
 namespace qps {
 
@@ -269,7 +270,22 @@ void launch_pass(hipStream_t st, bool check, int G, const T* A, int64_t ld, int 
                  const T* x_old, T* x_new, T* z, T* y, const T* l, const T* u, T alpha, T rho, T* part, T* part2,
                  int64_t part_ld, unsigned long long* slots, PassBatch pb) {
     if constexpr (MODE == 0) {
-        if (check) { hipLaunchKernelGGL((k_apass<T, THREADS, KC, RC, true, 0>), dim3(G, pb.count), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb); return; }
+        if (check) {
+            if (g_launch_timing.start) {
+                const LaunchTiming lt = g_launch_timing;
+                g_launch_timing = LaunchTiming();
+                hipExtLaunchKernelGGL((k_apass<T, THREADS, KC, RC, true, 0>), dim3(G, pb.count), dim3(THREADS), 0, st, lt.start, lt.stop, 0, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
+            } else {
+                hipLaunchKernelGGL((k_apass<T, THREADS, KC, RC, true, 0>), dim3(G, pb.count), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
+            }
+            return;
+        }
+    }
+    if (g_launch_timing.start) {   // profiled launch: timestamps of the dispatch itself
+        const LaunchTiming lt = g_launch_timing;
+        g_launch_timing = LaunchTiming();
+        hipExtLaunchKernelGGL((k_apass<T, THREADS, KC, R, false, MODE>), dim3(G, pb.count), dim3(THREADS), 0, st, lt.start, lt.stop, 0, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
+        return;
     }
     hipLaunchKernelGGL((k_apass<T, THREADS, KC, R, false, MODE>), dim3(G, pb.count), dim3(THREADS), 0, st, A, ld, NP, MP, rows_per_wg, xx, x_old, x_new, z, y, l, u, alpha, rho, part, part2, part_ld, slots, pb);
 }

@@ -5,6 +5,7 @@
 
 #include "qps_kernels.h"
 #include "wave_reduce.h"
+#include <hip/hip_ext.h>
 
 namespace qps {
 
@@ -154,7 +155,13 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
     const int G = sweep_fused_slabs<T>(NP, bs.count);
     dim3 grid(G, bs.count);
     const bool rb2 = (sweep_rb() == 2 && VecOf<T>::N == 2);
-#define QPS_S(KC, RB) hipLaunchKernelGGL((k_sweep_fused<T, TH, KC, RB>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs)
+    const LaunchTiming lt = g_launch_timing;   // profiled launch: the dispatch's own timestamps (qps_kernels.h)
+    g_launch_timing = LaunchTiming();
+#define QPS_S(KC, RB)                                                                                                              \
+    do {                                                                                                                           \
+        if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused<T, TH, KC, RB>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \
+        else hipLaunchKernelGGL((k_sweep_fused<T, TH, KC, RB>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs);            \
+    } while (0)
     if (rb2) { if (kc <= 1) QPS_S(1, 2); else if (kc <= 2) QPS_S(2, 2); else if (kc <= 4) QPS_S(4, 2); else QPS_S(8, 2); }
     else     { if (kc <= 1) QPS_S(1, 4); else if (kc <= 2) QPS_S(2, 4); else if (kc <= 4) QPS_S(4, 4); else QPS_S(8, 2 * (VecOf<T>::N / 2)); }
 #undef QPS_S

@@ -10,6 +10,19 @@
 
 using namespace qps;
 
+namespace qps {
+thread_local LaunchTiming g_launch_timing;
+ProfLaunchScope::ProfLaunchScope(Profiler& pr, int c, int lvl) : p(pr), cat(c), a(nullptr), b(nullptr), active(pr.on(lvl)) {
+    if (active) { a = p.get(); b = p.get(); g_launch_timing.start = a; g_launch_timing.stop = b; }
+}
+ProfLaunchScope::~ProfLaunchScope() {
+    if (!active) return;
+    const bool consumed = (g_launch_timing.start == nullptr);
+    g_launch_timing = LaunchTiming();
+    if (consumed) p.pending.push_back({cat, a, b}); else { p.pool.push_back(a); p.pool.push_back(b); }
+}
+}  // namespace qps
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -155,8 +168,8 @@ template <typename T> struct DenseSolver : SolverBase {
         if (nblk == 1 && sweep_mode == 2 && sweep_fused_supported<T>(NP)) {
             // one inverted block: forward and backward sweep read the same entries -> one fused pass over the triangle
             int G;
-            { ProfScope ps(prof, cat_sweep, sample_lvl(13)); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
-            { ProfScope ps(prof, cat_xsum, sample_lvl(21)); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
+            { ProfLaunchScope ps(prof, cat_sweep, sample_lvl(13)); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
+            { ProfLaunchScope ps(prof, cat_xsum, sample_lvl(21)); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
             return;
         }
         {
@@ -280,7 +293,7 @@ template <typename T> struct DenseSolver : SolverBase {
                 }
                 prof_iter = ii;
                 {
-                    ProfScope ps(prof, cat_colsum, sample_lvl(29));
+                    ProfLaunchScope ps(prof, cat_colsum, sample_lvl(29));
                     colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP);              // LinearSystemSolvers.jl:136
                 }
                 sweeps();                                                                           // :137
@@ -289,7 +302,7 @@ template <typename T> struct DenseSolver : SolverBase {
                     // level 1 samples the dominant kernel on every 50th iteration only (an event pair per launch costs ~7 % of
                     // the loop, one in ten still ~3 %); level 2 brackets every launch of every kernel
                     const int lvl = (prof.level == 1 && (check || ii % 50 != 38)) ? 3 : 1;   // mid-chunk sample of the plain variant only
-                    ProfScope ps(prof, check ? cat_passchk : cat_pass, lvl);
+                    ProfLaunchScope ps(prof, check ? cat_passchk : cat_pass, lvl);   // the dispatch's own begin / end timestamps
                     apass<T>(st, check, A, NP, NP, MP, xx, x, xp, z, y, l, u, (T)alpha, (T)rho, part, part2, NP, scratch);
                 }
                 std::swap(x, xp);   // x now holds the relaxed iterate, xp the previous one (SolveQuadraticProgram.jl:56-57)

@@ -49,6 +49,13 @@ struct Profiler {
     void reset() { for (auto& s : stats) { s.seconds = 0; s.launches = 0; } }
     ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } }
 };
+// Times ONE kernel dispatch by its own timestamps: the launcher called inside the scope consumes g_launch_timing (qps_kernels.h).
+// If no launcher consumed it (a code path without support), the sample is dropped.
+struct ProfLaunchScope {
+    Profiler& p; int cat; hipEvent_t a, b; bool active;
+    ProfLaunchScope(Profiler& pr, int c, int lvl);
+    ~ProfLaunchScope();
+};
 struct ProfScope {
     Profiler& p; int cat; hipEvent_t a; bool active;
     ProfScope(Profiler& pr, int c, int lvl) : p(pr), cat(c), a(nullptr), active(pr.on(lvl)) { if (active) p.begin(cat, a); }

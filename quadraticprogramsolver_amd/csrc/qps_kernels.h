@@ -16,6 +16,13 @@
 
 namespace qps {
 
+// A launcher that finds a pending event pair here attaches it to its kernel dispatch (hipExtLaunchKernelGGL): the events then carry the
+// kernel's own begin / end timestamps -- what rocprofv3 reports -- instead of bracketing the launch from outside (+3-4 us of
+// launch gap and event handling).  Thread-local: handles may be driven from different host threads.
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local LaunchTiming g_launch_timing;
+
+
 // Batched launches (BASELINE config 4: many independent QPs of one shape per GPU): blockIdx.y = QP index, element strides
 // between consecutive QPs for the matrix / input-vector / output-vector operands, optional per-QP active mask.
 // Default-constructed = the single-QP launch (count 1, no offsets).
