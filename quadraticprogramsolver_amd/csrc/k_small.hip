@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "qps_kernels.h"
+#include "wave_reduce.h"
 
 namespace qps {
 
@@ -197,6 +198,185 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// n <= 64, m <= 256: the matrices live in REGISTERS.  512 threads = 8 waves; lane = column (n-vectors) or row inside a block
+// of 64 (m-vectors), wave g owns the matrix rows g, g + 8, g + 16, ...  Every product of the iteration is a column
+// accumulation over register-resident entries whose vector operand comes by v_readlane from the lane that owns it
+// (wave-uniform index), followed by ONE cross-wave sum through LDS -- four barriers per iteration, no LDS read per matrix
+// entry (the LDS-resident version above reads every entry of A twice and of S once per iteration through the LDS pipe).
+//   a[r]     = A[g + 8 r][lane]           A' w  :  sum_r a[r] * w[g + 8 r]
+//   at[b][c] = A[64 b + lane][g + 8 c]    A x~  :  sum_c at[b][c] * x~[g + 8 c]
+//   s[r]     = S[g + 8 r][lane]           y = W t:  rows j = g + 8 r <= lane (upper part = W');  x~ = W' y: rows >= lane (lower part = W)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int MB>
+__global__ __launch_bounds__(512) void k_admm_small64(SmallArgs a, const T* __restrict__ A, const T* __restrict__ P, const T* __restrict__ S,
+                                                      const T* __restrict__ q, const T* __restrict__ l, const T* __restrict__ u,
+                                                      T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz, T* __restrict__ gy,
+                                                      SmallOut* __restrict__ out) {
+    constexpr int RA = 8 * MB;
+    __shared__ T scrN[2][8][64];
+    __shared__ T scrM[8][64 * MB];
+    __shared__ unsigned long long nrm[9];
+    __shared__ int sh_flag, sh_need;
+    __shared__ double sh_rhorho;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T ar[RA], at[MB][8], sr[8];
+#pragma unroll
+    for (int r = 0; r < RA; ++r) ar[r] = A[(int64_t)(g + 8 * r) * 64 + lane];
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) at[b][c] = A[(int64_t)(64 * b + lane) * 64 + g + 8 * c];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sr[r] = S[(int64_t)(g + 8 * r) * 64 + lane];
+    T x = gx[lane], xp = gxp[lane], xt = T(0);
+    const T qv = q[lane];
+    T z[MB], y[MB], zp[MB], lv[MB], uv[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) { z[b] = gz[64 * b + lane]; y[b] = gy[64 * b + lane]; zp[b] = T(0); lv[b] = l[64 * b + lane]; uv[b] = u[64 * b + lane]; }
+    if (tid == 0) { sh_flag = 1; sh_need = 0; sh_rhorho = a.rhorho; }
+    __syncthreads();
+    const T rho = (T)a.rho, rho1 = T(1) / rho, sigma = (T)a.sigma, alpha = (T)a.alpha, alpha1 = T(1) - alpha;
+    // out_j = sum over the 8 waves of sum_r ar[r] * v[g + 8 r]   (v: an m-vector held as MB lane-blocks)
+    auto atv = [&](const T (&v)[MB], T (*scr)[64]) -> T {
+        T p = T(0);
+#pragma unroll
+        for (int r = 0; r < RA; ++r) p += ar[r] * lane_get(v[r >> 3], g + 8 * (r & 7));
+        scr[g][lane] = p;
+        __syncthreads();
+        T t = T(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += scr[k][lane];
+        return t;
+    };
+    // out_i (MB blocks) = sum over the waves of sum_c at[b][c] * v[g + 8 c]   (v: an n-vector, one value per lane)
+    auto av = [&](T v, T (&outv)[MB]) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            T p = T(0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) p += at[b][c] * lane_get(v, g + 8 * c);
+            scrM[g][64 * b + lane] = p;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            T t = T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += scrM[k][64 * b + lane];
+            outv[b] = t;
+        }
+    };
+    int it = a.it_begin;
+    double res[8] = {NAN, NAN, NAN, NAN, a.rhorho, 1.0, NAN, NAN};
+    while (it < a.it_end) {
+        ++it;
+        T w[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) w[b] = rho * z[b] - y[b];                                    // LinearSystemSolvers.jl:134
+        T t = atv(w, scrN[0]);                                                                    // :135  A' w
+        t = sigma * x - qv + t;                                                                   // :136
+        T p = T(0);                                                                               // forward sweep  y = W t
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int j = g + 8 * r; const T tj = lane_get(t, j); if (j <= lane) p += sr[r] * tj; }
+        scrN[1][g][lane] = p;
+        __syncthreads();
+        T y1 = T(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y1 += scrN[1][k][lane];
+        p = T(0);                                                                                 // backward sweep  x~ = W' y
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = g + 8 * r; const T yi = lane_get(y1, i); if (i >= lane) p += sr[r] * yi; }
+        scrN[0][g][lane] = p;
+        __syncthreads();
+        xt = T(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xt += scrN[0][k][lane];
+        T zt[MB];
+        av(xt, zt);                                                                               // :139  z~ = A x~
+        xp = x; x = alpha * xt + alpha1 * x;                                                      // SolveQuadraticProgram.jl:56-57
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {                                                            // :59-61
+            const T zo = z[b], yo = y[b];
+            zp[b] = zo;
+            const T tt = alpha * zt[b] + alpha1 * zo + rho1 * yo;
+            const T zn = tt > uv[b] ? uv[b] : (tt < lv[b] ? lv[b] : tt);
+            z[b] = zn;
+            y[b] = yo + rho * (alpha * zt[b] + alpha1 * zo - zn);
+        }
+        if (it % a.numItrConv == 0) {                                                             // :63  CheckConvergence :79-112
+            T Ax[MB];
+            av(x, Ax);
+            T pp = T(0);                                                                          // P x (P symmetric: column accumulation over its rows)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pp += P[(int64_t)(g + 8 * r) * 64 + lane] * lane_get(x, g + 8 * r);
+            scrN[1][g][lane] = pp;
+            __syncthreads();
+            T Px = T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Px += scrN[1][k][lane];
+            const T Aty = atv(y, scrN[0]);
+            if (tid < 9) nrm[tid] = 0ull;
+            __syncthreads();
+            unsigned long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (g == 0) {                                                                         // every wave holds the same vectors: one wave reduces
+#pragma unroll
+                for (int b = 0; b < MB; ++b) {
+                    if (64 * b + lane < a.m) {
+                        v[0] = max(v[0], absbits_s((double)(Ax[b] - z[b]))); v[2] = max(v[2], absbits_s((double)Ax[b]));
+                        v[3] = max(v[3], absbits_s((double)z[b])); v[8] = max(v[8], absbits_s((double)(z[b] - zp[b])));
+                    }
+                }
+                if (lane < a.n) {
+                    v[1] = max(v[1], absbits_s((double)(Px + qv + Aty))); v[4] = max(v[4], absbits_s((double)Px));
+                    v[5] = max(v[5], absbits_s((double)Aty)); v[6] = max(v[6], absbits_s((double)qv));
+                    v[7] = max(v[7], absbits_s((double)(x - xp)));
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { const unsigned long long tv = __shfl_xor(v[k], o, 64); v[k] = tv > v[k] ? tv : v[k]; }
+                    if (lane == 0) nrm[k] = v[k];
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double nv[9];
+                for (int k = 0; k < 9; ++k) nv[k] = __longlong_as_double((long long)nrm[k]);
+                const double normResPrim = nv[0], normResDual = nv[1];                            // :85-86
+                const double maxNormPrim = jmax_s(nv[2], nv[3]);                                  // :88
+                const double maxNormDual = jmax_s(jmax_s(nv[4], nv[5]), nv[6]);                   // :89
+                double rr = sh_rhorho;
+                if (a.adptRho) {                                                                  // :92-96
+                    const double tv = a.rho * sqrt((normResPrim * maxNormDual) / (normResDual * maxNormPrim));
+                    rr = tv > 1e6 ? 1e6 : (tv < 1e-3 ? 1e-3 : tv);
+                }
+                int flag = 1;
+                if ((normResPrim < a.epsAbs + a.epsRel * maxNormPrim) && (normResDual < a.epsAbs + a.epsRel * maxNormDual)) flag = 3;   // :102-104
+                if ((nv[7] <= a.epsAdmm) && (nv[8] <= a.epsAdmm)) flag = 2;                       // :105-107 (not else)
+                sh_rhorho = rr; sh_flag = flag;
+                sh_need = (flag == 1 && a.adptRho && ((rr * a.fctrRho < a.rho) || (rr > a.fctrRho * a.rho))) ? 1 : 0;   // :47
+                res[0] = normResPrim; res[1] = normResDual; res[2] = maxNormPrim; res[3] = maxNormDual; res[4] = rr; res[5] = flag;
+                res[6] = nv[7]; res[7] = nv[8];
+            }
+            __syncthreads();
+            if (sh_flag != 1 || sh_need) break;
+        }
+    }
+    if (g == 0) {
+        gx[lane] = x; gxp[lane] = xp;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) { gz[64 * b + lane] = z[b]; gy[64 * b + lane] = y[b]; }
+    }
+    if (tid == 0) {
+        out->last_it = it; out->convFlag = sh_flag; out->need_rho = sh_need;
+        for (int k = 0; k < 8; ++k) out->res[k] = res[k];
+        out->res[4] = sh_rhorho;
+    }
+}
+
 // At[c][r] = A[r][c]  (A row-major MP x NP, At row-major NP x MP); sizes are small here
 template <typename T> __global__ void k_transpose_small(const T* __restrict__ A, int NP, int MP, T* __restrict__ At) {
     const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
@@ -220,6 +400,21 @@ void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int 
                 double rhorho, double sigma, double alpha, double epsAbs, double epsRel, double epsAdmm, double fctrRho, const T* A,
                 const T* At, const T* P, const T* S, const T* q, const T* l, const T* u, T* x, T* xp, T* z, T* y, void* out_dev) {
     SmallArgs a{n, m, NP, MP, it_begin, it_end, numItrConv, adptRho, rho, rhorho, sigma, alpha, epsAbs, epsRel, epsAdmm, fctrRho};
+    static const int reg_env = [] { const char* e = getenv("QPS_SMALL_REG"); return e ? atoi(e) : 1; }();
+    if (reg_env && NP == 64 && MP >= 64 && MP <= (sizeof(T) == 8 ? 128 : 256)) {   // matrices in registers (fp64 beyond m = 128 would spill)
+        SmallOut* o = reinterpret_cast<SmallOut*>(out_dev);
+        switch (MP / 64) {
+            case 1: hipLaunchKernelGGL((k_admm_small64<T, 1>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o); break;
+            case 2: hipLaunchKernelGGL((k_admm_small64<T, 2>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o); break;
+            default:
+                if constexpr (sizeof(T) == 4) {
+                    if (MP / 64 == 3) hipLaunchKernelGGL((k_admm_small64<T, 3>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o);
+                    else hipLaunchKernelGGL((k_admm_small64<T, 4>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o);
+                }
+                break;
+        }
+        return;
+    }
     size_t lds = small_lds_bytes<T>(NP, MP);
     static const int lm_env = [] { const char* e = getenv("QPS_SMALL_LDSMAT"); return e ? atoi(e) : 1; }();
     const bool lm = lm_env && (lds + small_lds_mat_bytes<T>(NP, MP) <= 158 * 1024);

@@ -49,6 +49,29 @@ template <typename T> struct DenseSolver : SolverBase {
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
     int nb = 2048; int part_tiles = 0; int num_factorizations = 0;
+    // hipGraph replay of runs of plain iterations (no check, no rho switch) for problems small enough to be launch bound
+    struct IterGraph { int count; const void* xa; double rho, sigma, alpha; int nb; hipGraphExec_t exec; };
+    std::vector<IterGraph> graphs;
+    void drop_graphs() { for (auto& gr : graphs) (void)hipGraphExecDestroy(gr.exec); graphs.clear(); }
+    // `count` (even) plain iterations of the fused loop starting with x in `xa`, xp in `xb`; captured once per (count, roles, scalars)
+    hipGraphExec_t iter_graph(int count, T* xa, T* xb, double rho, double sigma, double alpha) {
+        for (auto& gr : graphs) if (gr.count == count && gr.xa == xa && gr.rho == rho && gr.sigma == sigma && gr.alpha == alpha && gr.nb == nb) return gr.exec;
+        if (graphs.size() >= 8) drop_graphs();
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        HIPC(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < count; ++k) {
+            colsum<T>(st, part, NP, pass_slabs, xa, (T)sigma, q, T(-1), tt, NP);                    // LinearSystemSolvers.jl:136
+            sweeps();                                                                               // :137 (profiling is off here: plain launches)
+            apass<T>(st, false, A, NP, NP, MP, xx, xa, xb, z, y, l, u, (T)alpha, (T)rho, part, part2, NP, scratch);   // :56-61, :139, next :134-135
+            std::swap(xa, xb);
+        }
+        HIPC(hipStreamEndCapture(st, &graph));
+        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) throw QpsError(QPS_ERR_HIP, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+        graphs.push_back({count, xa, rho, sigma, alpha, nb, exec});   // (xa is back in its original role: count is even)
+        return exec;
+    }
     int prof_iter = 0;   // iteration index seen by the level-1 sampler (one bracketed launch per kernel kind per 50 iterations)
     int sample_lvl(int slot) const { return (prof.level == 1 && prof_iter % 50 == slot) ? 1 : 2; }
     int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk, cat_sweep, cat_xsum;
@@ -101,6 +124,7 @@ template <typename T> struct DenseSolver : SolverBase {
     ~DenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
+        drop_graphs();
         void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, sw_part, Ax, Px, Aty, scratch, res_dev, stage, At, small_out};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (res_host) (void)hipHostFree(res_host);
@@ -260,6 +284,10 @@ template <typename T> struct DenseSolver : SolverBase {
         }
         const bool fused = pass_slabs > 0 && p.loopVariant != 1;
         int rhs_slabs = 0;   // z = y = 0: A'(rho z - y) = 0, no slab to add for the first right-hand side
+        // Launch-bound sizes (an iteration of four to eight kernels lasts less than the host needs to enqueue it): replay graphs.
+        // Profiling brackets launches and stays eager.
+        static const int graph_env = [] { const char* e = getenv("QPS_GRAPH"); return e ? atoi(e) : -1; }();
+        const bool use_graph = fused && prof.level == 0 && p.numItrConv >= 3 && (graph_env >= 0 ? graph_env != 0 : NP <= 2048);
         for (ii = 1; ii <= p.numIterations; ++ii) {                                                 // :45
             bool changed = false;
             if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {          // :47
@@ -269,6 +297,15 @@ template <typename T> struct DenseSolver : SolverBase {
                 tref += now_s() - ta;
             }
             const bool check = (ii % p.numItrConv == 0);                                            // :63
+            if (use_graph && !changed && !check && rhs_slabs == pass_slabs) {
+                // the plain iterations up to the next check (an even number of them, so x / xp end in the same roles) as ONE graph launch
+                int run = std::min(p.numItrConv - ii % p.numItrConv, p.numIterations - ii + 1) & ~1;
+                if (run >= 2) {
+                    HIPC(hipGraphLaunch(iter_graph(run, x, xp, rho, sigma, alpha), st));
+                    ii += run - 1;
+                    continue;
+                }
+            }
             if (!fused) {
                 linear_solve(rho, sigma);                                                           // :54
                 {

@@ -475,8 +475,8 @@ def test_concurrent_handles_from_two_host_threads(gpu, c_oracle):
             assert flag == io["convFlag"] and its == io["iterations"] and np.abs(x - xo).max() <= ABS_DEV_THR
 
 
-KNOBS = [{"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
-         {"QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"}]
+KNOBS = [{"QPS_GRAPH": "0"}, {"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
+         {"QPS_SMALL_REG": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"}]
 
 
 @pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
