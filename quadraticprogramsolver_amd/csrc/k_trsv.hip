@@ -62,10 +62,15 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
                     for (int e = 0; e < VN; ++e) p[e] = T(0); }
             }
     };
+    // A wave whose first column lies right of the diagonal holds only zeros of this row: it skips the dot, the reduction and the
+    // accumulation (wave-uniform test) and only meets the barrier -- on the narrow batched problems half the waves of a row.
+    constexpr bool SKIP = KC <= 2;          // wide problems (KC = 4: C2) lose more to the extra branches than the few idle waves cost
+    const int wave_col0 = (tid & ~63) * VN;
     auto process = [&](V (&a)[RB][KC], int row, int par) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             T s = T(0);
+            if (SKIP && wave_col0 > row + i) { if ((tid & 63) == 0) red[par][tid >> 6][i] = T(0); continue; }
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 const int c = tid * VN + k * CHUNK;
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
             // lanes 0..WAVES-1 fetch one per-wave partial each (one LDS read per row and wave instead of WAVES broadcast reads per
             // thread); fixed order, identical in every wave
             static_assert(WAVES <= 8, "one partial per lane of the first eight");
+            if (SKIP && wave_col0 > row + i) continue;
             const T y = lanes8_sum_all(((tid & 63) < WAVES) ? red[par][tid & 63][i] : T(0));
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
