@@ -165,10 +165,16 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int6
 #pragma unroll
     for (int e = 0; e < VN; ++e) red[tl][cl * VN + e] = acc[e];
     __syncthreads();
-    const int oc = blockIdx.x * 16 + threadIdx.x;
-    if (threadIdx.x < 16 && oc < ncols) {
-        T s = T(0);
-        for (int t = 0; t < TL; ++t) s += red[t][threadIdx.x];   // fixed order -> bitwise reproducible
+    // 16 outputs x 16 lanes: every lane adds TL / 16 partials, a DPP row sum finishes in lane 15 of the row (fixed order -> bitwise
+    // reproducible; the serial walk over TL partials by 16 threads was ~1 us of a 4.7 us kernel)
+    static_assert(TL % 16 == 0, "slab lanes per output");
+    const int o = threadIdx.x >> 4, pl = threadIdx.x & 15;
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < TL / 16; ++k) s += red[pl * (TL / 16) + k][o];
+    s = row16_sum_last(s);
+    const int oc = blockIdx.x * 16 + o;
+    if (pl == 15 && oc < ncols) {
         T r = s;
         if (a0) r += s0 * a0[oc];
         if (a1) r += s1 * a1[oc];

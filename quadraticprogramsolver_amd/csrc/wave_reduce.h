@@ -45,6 +45,15 @@ template <typename T> __device__ __forceinline__ T lanes8_sum_all(T a) {
     return lane_get(t, 7);
 }
 
+// sum over each aligned row of 16 lanes; the total is valid in lane 15 of the row (other lanes hold partial prefixes)
+template <typename T> __device__ __forceinline__ T row16_sum_last(T a) {
+    T t = a + dpp_get<0x111, 0xf, 0xf>(a);
+    t = t + dpp_get<0x112, 0xf, 0xf>(a);
+    t = t + dpp_get<0x113, 0xf, 0xf>(a);
+    t = t + dpp_get<0x114, 0xf, 0xe>(t);
+    t = t + dpp_get<0x118, 0xf, 0xc>(t);
+    return t;
+}
 // all-reduce sums over aligned groups of 4 / 8 lanes, every lane of the group gets the total (DPP quad_perm / row_half_mirror)
 template <typename T> __device__ __forceinline__ T quad_sum_all(T v) {
     v = v + dpp_get<0xB1, 0xf, 0xf>(v);             // quad_perm [1,0,3,2]
