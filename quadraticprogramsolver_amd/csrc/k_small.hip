@@ -200,7 +200,7 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// n <= 64, m <= 256: the matrices live in REGISTERS.  512 threads = 8 waves; lane = column (n-vectors) or row inside a block
+// n <= 128, small m: the matrices live in REGISTERS.  512 threads = 8 waves; lane = column (n-vectors) or row inside a block
 // of 64 (m-vectors), wave g owns the matrix rows g, g + 8, g + 16, ...  Every product of the iteration is a column
 // accumulation over register-resident entries whose vector operand comes by v_readlane from the lane that owns it
 // (wave-uniform index), followed by ONE cross-wave sum through LDS -- four barriers per iteration, no LDS read per matrix
@@ -209,57 +209,78 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
 //   at[b][c] = A[64 b + lane][g + 8 c]    A x~  :  sum_c at[b][c] * x~[g + 8 c]
 //   s[r]     = S[g + 8 r][lane]           y = W t:  rows j = g + 8 r <= lane (upper part = W');  x~ = W' y: rows >= lane (lower part = W)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int MB>
-__global__ __launch_bounds__(512) void k_admm_small64(SmallArgs a, const T* __restrict__ A, const T* __restrict__ P, const T* __restrict__ S,
-                                                      const T* __restrict__ q, const T* __restrict__ l, const T* __restrict__ u,
-                                                      T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz, T* __restrict__ gy,
-                                                      SmallOut* __restrict__ out) {
-    constexpr int RA = 8 * MB;
-    __shared__ T scrN[2][8][64];
+template <typename T, int NB, int MB>      // NB = n padded / 64 (1 or 2), MB = m padded / 64
+__global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __restrict__ A, const T* __restrict__ P, const T* __restrict__ S,
+                                                        const T* __restrict__ q, const T* __restrict__ l, const T* __restrict__ u,
+                                                        T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz, T* __restrict__ gy,
+                                                        SmallOut* __restrict__ out) {
+    constexpr int NPc = 64 * NB, RA = 8 * MB, RS = 8 * NB;          // rows of A / S per wave
+    __shared__ T scrN[2][8][NPc];
     __shared__ T scrM[8][64 * MB];
     __shared__ unsigned long long nrm[9];
     __shared__ int sh_flag, sh_need;
     __shared__ double sh_rhorho;
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-    T ar[RA], at[MB][8], sr[8];
+    T ar[RA][NB], at[MB][RS], sr[RS][NB];
 #pragma unroll
-    for (int r = 0; r < RA; ++r) ar[r] = A[(int64_t)(g + 8 * r) * 64 + lane];
+    for (int r = 0; r < RA; ++r)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) ar[r][c] = A[(int64_t)(g + 8 * r) * NPc + 64 * c + lane];
 #pragma unroll
     for (int b = 0; b < MB; ++b)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) at[b][c] = A[(int64_t)(64 * b + lane) * 64 + g + 8 * c];
+        for (int c = 0; c < RS; ++c) at[b][c] = A[(int64_t)(64 * b + lane) * NPc + g + 8 * c];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) sr[r] = S[(int64_t)(g + 8 * r) * 64 + lane];
-    T x = gx[lane], xp = gxp[lane], xt = T(0);
-    const T qv = q[lane];
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) sr[r][c] = S[(int64_t)(g + 8 * r) * NPc + 64 * c + lane];
+    T x[NB], xp[NB], xt[NB], qv[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { x[c] = gx[64 * c + lane]; xp[c] = gxp[64 * c + lane]; xt[c] = T(0); qv[c] = q[64 * c + lane]; }
     T z[MB], y[MB], zp[MB], lv[MB], uv[MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) { z[b] = gz[64 * b + lane]; y[b] = gy[64 * b + lane]; zp[b] = T(0); lv[b] = l[64 * b + lane]; uv[b] = u[64 * b + lane]; }
     if (tid == 0) { sh_flag = 1; sh_need = 0; sh_rhorho = a.rhorho; }
     __syncthreads();
     const T rho = (T)a.rho, rho1 = T(1) / rho, sigma = (T)a.sigma, alpha = (T)a.alpha, alpha1 = T(1) - alpha;
-    // out_j = sum over the 8 waves of sum_r ar[r] * v[g + 8 r]   (v: an m-vector held as MB lane-blocks)
-    auto atv = [&](const T (&v)[MB], T (*scr)[64]) -> T {
-        T p = T(0);
+    // entry i of a vector held as lane-blocks of 64 (i is wave-uniform)
+    auto nget = [&](const T (&v)[NB], int i) -> T { return NB == 1 ? lane_get(v[0], i) : ((i < 64) ? lane_get(v[0], i) : lane_get(v[NB - 1], i - 64)); };
+    // out (n-vector) = sum over the 8 waves of sum_r ar[r][.] * v[g + 8 r]   (v: an m-vector held as MB lane-blocks)
+    auto atv = [&](const T (&v)[MB], T (*scr)[NPc], T (&outv)[NB]) {
+        T p[NB];
 #pragma unroll
-        for (int r = 0; r < RA; ++r) p += ar[r] * lane_get(v[r >> 3], g + 8 * (r & 7));
-        scr[g][lane] = p;
-        __syncthreads();
-        T t = T(0);
+        for (int c = 0; c < NB; ++c) p[c] = T(0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += scr[k][lane];
-        return t;
-    };
-    // out_i (MB blocks) = sum over the waves of sum_c at[b][c] * v[g + 8 c]   (v: an n-vector, one value per lane)
-    auto av = [&](T v, T (&outv)[MB]) {
+        for (int r = 0; r < RA; ++r) {
+            const T vi = lane_get(v[r >> 3], g + 8 * (r & 7));
 #pragma unroll
-        for (int b = 0; b < MB; ++b) {
-            T p = T(0);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) p += at[b][c] * lane_get(v, g + 8 * c);
-            scrM[g][64 * b + lane] = p;
+            for (int c = 0; c < NB; ++c) p[c] += ar[r][c] * vi;
         }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) scr[g][64 * c + lane] = p[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            T t = T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += scr[k][64 * c + lane];
+            outv[c] = t;
+        }
+    };
+    // out (m-vector) = sum over the waves of sum_c at[b][c] * v[g + 8 c]   (v: an n-vector)
+    auto av = [&](const T (&v)[NB], T (&outv)[MB]) {
+        T pm[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) pm[b] = T(0);
+#pragma unroll
+        for (int c = 0; c < RS; ++c) {
+            const T vj = nget(v, g + 8 * c);
+#pragma unroll
+            for (int b = 0; b < MB; ++b) pm[b] += at[b][c] * vj;
+        }
+#pragma unroll
+        for (int b = 0; b < MB; ++b) scrM[g][64 * b + lane] = pm[b];
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < MB; ++b) {
@@ -269,34 +290,48 @@ __global__ __launch_bounds__(512) void k_admm_small64(SmallArgs a, const T* __re
             outv[b] = t;
         }
     };
+    // out (n-vector) = cross-wave sum of per-thread partials p[.]
+    auto nsum = [&](const T (&p)[NB], T (*scr)[NPc], T (&outv)[NB]) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) scr[g][64 * c + lane] = p[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            T t = T(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += scr[k][64 * c + lane];
+            outv[c] = t;
+        }
+    };
     int it = a.it_begin;
     double res[8] = {NAN, NAN, NAN, NAN, a.rhorho, 1.0, NAN, NAN};
     while (it < a.it_end) {
         ++it;
-        T w[MB];
+        T w[MB], t[NB], y1[NB], p[NB], zt[MB];
 #pragma unroll
         for (int b = 0; b < MB; ++b) w[b] = rho * z[b] - y[b];                                    // LinearSystemSolvers.jl:134
-        T t = atv(w, scrN[0]);                                                                    // :135  A' w
-        t = sigma * x - qv + t;                                                                   // :136
-        T p = T(0);                                                                               // forward sweep  y = W t
+        atv(w, scrN[0], t);                                                                       // :135  A' w
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { const int j = g + 8 * r; const T tj = lane_get(t, j); if (j <= lane) p += sr[r] * tj; }
-        scrN[1][g][lane] = p;
-        __syncthreads();
-        T y1 = T(0);
+        for (int c = 0; c < NB; ++c) { t[c] = sigma * x[c] - qv[c] + t[c]; p[c] = T(0); }         // :136
 #pragma unroll
-        for (int k = 0; k < 8; ++k) y1 += scrN[1][k][lane];
-        p = T(0);                                                                                 // backward sweep  x~ = W' y
+        for (int r = 0; r < RS; ++r) {                                                            // forward sweep  y = W t  (upper part = W')
+            const int j = g + 8 * r; const T tj = nget(t, j);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { const int i = g + 8 * r; const T yi = lane_get(y1, i); if (i >= lane) p += sr[r] * yi; }
-        scrN[0][g][lane] = p;
-        __syncthreads();
-        xt = T(0);
+            for (int c = 0; c < NB; ++c) if (j <= 64 * c + lane) p[c] += sr[r][c] * tj;
+        }
+        nsum(p, scrN[1], y1);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xt += scrN[0][k][lane];
-        T zt[MB];
+        for (int c = 0; c < NB; ++c) p[c] = T(0);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {                                                            // backward sweep  x~ = W' y  (lower part = W)
+            const int i = g + 8 * r; const T yi = nget(y1, i);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) if (i >= 64 * c + lane) p[c] += sr[r][c] * yi;
+        }
+        nsum(p, scrN[0], xt);
         av(xt, zt);                                                                               // :139  z~ = A x~
-        xp = x; x = alpha * xt + alpha1 * x;                                                      // SolveQuadraticProgram.jl:56-57
+#pragma unroll
+        for (int c = 0; c < NB; ++c) { xp[c] = x[c]; x[c] = alpha * xt[c] + alpha1 * x[c]; }      // SolveQuadraticProgram.jl:56-57
 #pragma unroll
         for (int b = 0; b < MB; ++b) {                                                            // :59-61
             const T zo = z[b], yo = y[b];
@@ -307,17 +342,18 @@ __global__ __launch_bounds__(512) void k_admm_small64(SmallArgs a, const T* __re
             y[b] = yo + rho * (alpha * zt[b] + alpha1 * zo - zn);
         }
         if (it % a.numItrConv == 0) {                                                             // :63  CheckConvergence :79-112
-            T Ax[MB];
+            T Ax[MB], Px[NB], Aty[NB];
             av(x, Ax);
-            T pp = T(0);                                                                          // P x (P symmetric: column accumulation over its rows)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) pp += P[(int64_t)(g + 8 * r) * 64 + lane] * lane_get(x, g + 8 * r);
-            scrN[1][g][lane] = pp;
-            __syncthreads();
-            T Px = T(0);
+            for (int c = 0; c < NB; ++c) p[c] = T(0);
+#pragma unroll 2
+            for (int r = 0; r < RS; ++r) {                                                        // P x (P symmetric: column accumulation over its rows); rare path: keep its register footprint small
+                const T xi = nget(x, g + 8 * r);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) Px += scrN[1][k][lane];
-            const T Aty = atv(y, scrN[0]);
+                for (int c = 0; c < NB; ++c) p[c] += P[(int64_t)(g + 8 * r) * NPc + 64 * c + lane] * xi;
+            }
+            nsum(p, scrN[1], Px);
+            atv(y, scrN[0], Aty);
             if (tid < 9) nrm[tid] = 0ull;
             __syncthreads();
             unsigned long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -329,10 +365,13 @@ __global__ __launch_bounds__(512) void k_admm_small64(SmallArgs a, const T* __re
                         v[3] = max(v[3], absbits_s((double)z[b])); v[8] = max(v[8], absbits_s((double)(z[b] - zp[b])));
                     }
                 }
-                if (lane < a.n) {
-                    v[1] = max(v[1], absbits_s((double)(Px + qv + Aty))); v[4] = max(v[4], absbits_s((double)Px));
-                    v[5] = max(v[5], absbits_s((double)Aty)); v[6] = max(v[6], absbits_s((double)qv));
-                    v[7] = max(v[7], absbits_s((double)(x - xp)));
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    if (64 * c + lane < a.n) {
+                        v[1] = max(v[1], absbits_s((double)(Px[c] + qv[c] + Aty[c]))); v[4] = max(v[4], absbits_s((double)Px[c]));
+                        v[5] = max(v[5], absbits_s((double)Aty[c])); v[6] = max(v[6], absbits_s((double)qv[c]));
+                        v[7] = max(v[7], absbits_s((double)(x[c] - xp[c])));
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
@@ -366,7 +405,8 @@ __global__ __launch_bounds__(512) void k_admm_small64(SmallArgs a, const T* __re
         }
     }
     if (g == 0) {
-        gx[lane] = x; gxp[lane] = xp;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) { gx[64 * c + lane] = x[c]; gxp[64 * c + lane] = xp[c]; }
 #pragma unroll
         for (int b = 0; b < MB; ++b) { gz[64 * b + lane] = z[b]; gy[64 * b + lane] = y[b]; }
     }
@@ -401,19 +441,23 @@ void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int 
                 const T* At, const T* P, const T* S, const T* q, const T* l, const T* u, T* x, T* xp, T* z, T* y, void* out_dev) {
     SmallArgs a{n, m, NP, MP, it_begin, it_end, numItrConv, adptRho, rho, rhorho, sigma, alpha, epsAbs, epsRel, epsAdmm, fctrRho};
     static const int reg_env = [] { const char* e = getenv("QPS_SMALL_REG"); return e ? atoi(e) : 1; }();
-    if (reg_env && NP == 64 && MP >= 64 && MP <= (sizeof(T) == 8 ? 128 : 256)) {   // matrices in registers (fp64 beyond m = 128 would spill)
+    // matrices in registers: n <= 64 with m <= 128 (fp64) / 256 (fp32); n <= 128 with m <= 64 (fp64) / 128 (fp32) -- beyond that the
+    // per-thread share of A (twice) and S no longer fits the 256 VGPRs of an 8-wave workgroup without spilling
+    if (reg_env && MP >= 64 && (NP == 64 || NP == 128)) {
         SmallOut* o = reinterpret_cast<SmallOut*>(out_dev);
-        switch (MP / 64) {
-            case 1: hipLaunchKernelGGL((k_admm_small64<T, 1>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o); break;
-            case 2: hipLaunchKernelGGL((k_admm_small64<T, 2>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o); break;
-            default:
-                if constexpr (sizeof(T) == 4) {
-                    if (MP / 64 == 3) hipLaunchKernelGGL((k_admm_small64<T, 3>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o);
-                    else hipLaunchKernelGGL((k_admm_small64<T, 4>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o);
-                }
-                break;
+        const int mb = MP / 64, mb_max = (NP == 64) ? (sizeof(T) == 8 ? 2 : 4) : (sizeof(T) == 8 ? 1 : 2);
+#define QPS_REG(NBv, MBv) hipLaunchKernelGGL((k_admm_small_reg<T, NBv, MBv>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o)
+        if (mb <= mb_max) {
+            if (NP == 64) {
+                if (mb == 1) QPS_REG(1, 1); else if (mb == 2) QPS_REG(1, 2);
+                else if constexpr (sizeof(T) == 4) { if (mb == 3) QPS_REG(1, 3); else QPS_REG(1, 4); }
+            } else {
+                if (mb == 1) QPS_REG(2, 1);
+                else if constexpr (sizeof(T) == 4) QPS_REG(2, 2);
+            }
+            return;
         }
-        return;
+#undef QPS_REG
     }
     size_t lds = small_lds_bytes<T>(NP, MP);
     static const int lm_env = [] { const char* e = getenv("QPS_SMALL_LDSMAT"); return e ? atoi(e) : 1; }();
