@@ -52,23 +52,26 @@ template <typename T> struct DenseSolver : SolverBase {
     // hipGraph replay of runs of plain iterations (no check, no rho switch) for problems small enough to be launch bound
     struct IterGraph { int count; const void* xa; double rho, sigma, alpha; int nb; hipGraphExec_t exec; };
     std::vector<IterGraph> graphs;
+    bool graphs_disabled = false;
     void drop_graphs() { for (auto& gr : graphs) (void)hipGraphExecDestroy(gr.exec); graphs.clear(); }
     // `count` (even) plain iterations of the fused loop starting with x in `xa`, xp in `xb`; captured once per (count, roles, scalars)
     hipGraphExec_t iter_graph(int count, T* xa, T* xb, double rho, double sigma, double alpha) {
         for (auto& gr : graphs) if (gr.count == count && gr.xa == xa && gr.rho == rho && gr.sigma == sigma && gr.alpha == alpha && gr.nb == nb) return gr.exec;
+        if (graphs_disabled) return nullptr;
         if (graphs.size() >= 8) drop_graphs();
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        HIPC(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graphs_disabled = true; return nullptr; }
         for (int k = 0; k < count; ++k) {
             colsum<T>(st, part, NP, pass_slabs, xa, (T)sigma, q, T(-1), tt, NP);                    // LinearSystemSolvers.jl:136
             sweeps();                                                                               // :137 (profiling is off here: plain launches)
             apass<T>(st, false, A, NP, NP, MP, xx, xa, xb, z, y, l, u, (T)alpha, (T)rho, part, part2, NP, scratch);   // :56-61, :139, next :134-135
             std::swap(xa, xb);
         }
-        HIPC(hipStreamEndCapture(st, &graph));
+        // nothing was enqueued while capturing, so a failure here just means: run this handle's iterations eagerly from now on
+        if (hipStreamEndCapture(st, &graph) != hipSuccess || graph == nullptr) { (void)hipGetLastError(); graphs_disabled = true; return nullptr; }
         const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) throw QpsError(QPS_ERR_HIP, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipGetLastError(); graphs_disabled = true; return nullptr; }
         graphs.push_back({count, xa, rho, sigma, alpha, nb, exec});   // (xa is back in its original role: count is even)
         return exec;
     }
@@ -300,8 +303,9 @@ template <typename T> struct DenseSolver : SolverBase {
             if (use_graph && !changed && !check && rhs_slabs == pass_slabs) {
                 // the plain iterations up to the next check (an even number of them, so x / xp end in the same roles) as ONE graph launch
                 int run = std::min(p.numItrConv - ii % p.numItrConv, p.numIterations - ii + 1) & ~1;
-                if (run >= 2) {
-                    HIPC(hipGraphLaunch(iter_graph(run, x, xp, rho, sigma, alpha), st));
+                hipGraphExec_t ge = run >= 2 ? iter_graph(run, x, xp, rho, sigma, alpha) : nullptr;
+                if (ge) {
+                    HIPC(hipGraphLaunch(ge, st));
                     ii += run - 1;
                     continue;
                 }
