@@ -220,6 +220,7 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
     __shared__ unsigned long long nrm[9];
     __shared__ int sh_flag, sh_need;
     __shared__ double sh_rhorho;
+    __shared__ double sres[8];                 // written by thread 0 only: kept out of everybody's registers
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     T ar[RA][NB], at[MB][RS], sr[RS][NB];
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
 #pragma unroll
     for (int b = 0; b < MB; ++b) { z[b] = gz[64 * b + lane]; y[b] = gy[64 * b + lane]; zp[b] = T(0); lv[b] = l[64 * b + lane]; uv[b] = u[64 * b + lane]; }
     if (tid == 0) { sh_flag = 1; sh_need = 0; sh_rhorho = a.rhorho; }
+    if (tid < 8) sres[tid] = (tid == 4) ? a.rhorho : (tid == 5 ? 1.0 : (double)NAN);
     __syncthreads();
     const T rho = (T)a.rho, rho1 = T(1) / rho, sigma = (T)a.sigma, alpha = (T)a.alpha, alpha1 = T(1) - alpha;
     // entry i of a vector held as lane-blocks of 64 (i is wave-uniform)
@@ -304,7 +306,6 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
         }
     };
     int it = a.it_begin;
-    double res[8] = {NAN, NAN, NAN, NAN, a.rhorho, 1.0, NAN, NAN};
     while (it < a.it_end) {
         ++it;
         T w[MB], t[NB], y1[NB], p[NB], zt[MB];
@@ -356,29 +357,41 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
             atv(y, scrN[0], Aty);
             if (tid < 9) nrm[tid] = 0ull;
             __syncthreads();
-            unsigned long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (g == 0) {                                                                         // every wave holds the same vectors: one wave reduces
+                // one norm at a time (the nine maxima alive together cost 18 VGPRs of a kernel that is at its register limit)
+                auto put = [&](int k, unsigned long long v) {
 #pragma unroll
-                for (int b = 0; b < MB; ++b) {
-                    if (64 * b + lane < a.m) {
-                        v[0] = max(v[0], absbits_s((double)(Ax[b] - z[b]))); v[2] = max(v[2], absbits_s((double)Ax[b]));
-                        v[3] = max(v[3], absbits_s((double)z[b])); v[8] = max(v[8], absbits_s((double)(z[b] - zp[b])));
-                    }
-                }
+                    for (int o = 32; o > 0; o >>= 1) { const unsigned long long tv = __shfl_xor(v, o, 64); v = tv > v ? tv : v; }
+                    if (lane == 0) nrm[k] = v;
+                };
+                unsigned long long v = 0;
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    if (64 * c + lane < a.n) {
-                        v[1] = max(v[1], absbits_s((double)(Px[c] + qv[c] + Aty[c]))); v[4] = max(v[4], absbits_s((double)Px[c]));
-                        v[5] = max(v[5], absbits_s((double)Aty[c])); v[6] = max(v[6], absbits_s((double)qv[c]));
-                        v[7] = max(v[7], absbits_s((double)(x[c] - xp[c])));
-                    }
-                }
+                for (int b = 0; b < MB; ++b) if (64 * b + lane < a.m) v = max(v, absbits_s((double)(Ax[b] - z[b])));
+                put(0, v); v = 0;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int b = 0; b < MB; ++b) if (64 * b + lane < a.m) v = max(v, absbits_s((double)Ax[b]));
+                put(2, v); v = 0;
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { const unsigned long long tv = __shfl_xor(v[k], o, 64); v[k] = tv > v[k] ? tv : v[k]; }
-                    if (lane == 0) nrm[k] = v[k];
-                }
+                for (int b = 0; b < MB; ++b) if (64 * b + lane < a.m) v = max(v, absbits_s((double)z[b]));
+                put(3, v); v = 0;
+#pragma unroll
+                for (int b = 0; b < MB; ++b) if (64 * b + lane < a.m) v = max(v, absbits_s((double)(z[b] - zp[b])));
+                put(8, v); v = 0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (64 * c + lane < a.n) v = max(v, absbits_s((double)(Px[c] + qv[c] + Aty[c])));
+                put(1, v); v = 0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (64 * c + lane < a.n) v = max(v, absbits_s((double)Px[c]));
+                put(4, v); v = 0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (64 * c + lane < a.n) v = max(v, absbits_s((double)Aty[c]));
+                put(5, v); v = 0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (64 * c + lane < a.n) v = max(v, absbits_s((double)qv[c]));
+                put(6, v); v = 0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (64 * c + lane < a.n) v = max(v, absbits_s((double)(x[c] - xp[c])));
+                put(7, v);
             }
             __syncthreads();
             if (tid == 0) {
@@ -397,8 +410,8 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
                 if ((nv[7] <= a.epsAdmm) && (nv[8] <= a.epsAdmm)) flag = 2;                       // :105-107 (not else)
                 sh_rhorho = rr; sh_flag = flag;
                 sh_need = (flag == 1 && a.adptRho && ((rr * a.fctrRho < a.rho) || (rr > a.fctrRho * a.rho))) ? 1 : 0;   // :47
-                res[0] = normResPrim; res[1] = normResDual; res[2] = maxNormPrim; res[3] = maxNormDual; res[4] = rr; res[5] = flag;
-                res[6] = nv[7]; res[7] = nv[8];
+                sres[0] = normResPrim; sres[1] = normResDual; sres[2] = maxNormPrim; sres[3] = maxNormDual; sres[4] = rr; sres[5] = flag;
+                sres[6] = nv[7]; sres[7] = nv[8];
             }
             __syncthreads();
             if (sh_flag != 1 || sh_need) break;
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
     }
     if (tid == 0) {
         out->last_it = it; out->convFlag = sh_flag; out->need_rho = sh_need;
-        for (int k = 0; k < 8; ++k) out->res[k] = res[k];
+        for (int k = 0; k < 8; ++k) out->res[k] = sres[k];
         out->res[4] = sh_rhorho;
     }
 }
@@ -445,15 +458,15 @@ void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int 
     // per-thread share of A (twice) and S no longer fits the 256 VGPRs of an 8-wave workgroup without spilling
     if (reg_env && MP >= 64 && (NP == 64 || NP == 128)) {
         SmallOut* o = reinterpret_cast<SmallOut*>(out_dev);
-        const int mb = MP / 64, mb_max = (NP == 64) ? (sizeof(T) == 8 ? 2 : 4) : (sizeof(T) == 8 ? 1 : 2);
+        const int mb = MP / 64, mb_max = sizeof(T) == 8 ? 2 : 4;
 #define QPS_REG(NBv, MBv) hipLaunchKernelGGL((k_admm_small_reg<T, NBv, MBv>), dim3(1), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o)
         if (mb <= mb_max) {
             if (NP == 64) {
                 if (mb == 1) QPS_REG(1, 1); else if (mb == 2) QPS_REG(1, 2);
                 else if constexpr (sizeof(T) == 4) { if (mb == 3) QPS_REG(1, 3); else QPS_REG(1, 4); }
             } else {
-                if (mb == 1) QPS_REG(2, 1);
-                else if constexpr (sizeof(T) == 4) QPS_REG(2, 2);
+                if (mb == 1) QPS_REG(2, 1); else if (mb == 2) QPS_REG(2, 2);
+                else if constexpr (sizeof(T) == 4) { if (mb == 3) QPS_REG(2, 3); else QPS_REG(2, 4); }
             }
             return;
         }

@@ -475,6 +475,31 @@ def test_concurrent_handles_from_two_host_threads(gpu, c_oracle):
             assert flag == io["convFlag"] and its == io["iterations"] and np.abs(x - xo).max() <= ABS_DEV_THR
 
 
+@pytest.mark.parametrize("dtype,n,m", [("f64", 10, 5), ("f64", 64, 128), ("f64", 100, 50), ("f64", 100, 100), ("f64", 128, 128),
+                                         ("f32", 64, 256), ("f32", 100, 200), ("f32", 128, 128)])
+def test_register_resident_single_launch_kernel(gpu, c_oracle, dtype, n, m):
+    """Every instantiation of the register-resident single-launch kernel (n <= 128; one or two column blocks, one to four row
+    blocks) against the oracle: iterates and residuals after fixed K, and a full adaptive-rho solve (the kernel returns to the
+    host for every rho switch and is relaunched) with the same flag, iteration and refactor counts."""
+    P, q, A, l, u = GenerateDenseBenchmarkQP(n, m, stream=21, feasible=True)
+    tol = 1e-9 if dtype == "f64" else 2e-3
+    with gpu.QuadraticProgram(P, q, A, l, u, dtype=dtype) as prob:
+        for K in (25, 60):
+            x = np.zeros(n); info = {}
+            prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+            z, y = prob.dual()
+            xo, io = c_oracle.solve(P, q, A, l, u, numIterations=K, epsAbs=0.0, epsRel=0.0, rho=0.1)
+            assert rel(x, xo) <= tol and rel(z, io["z"]) <= tol and rel(y, io["y"]) <= 10 * tol
+            assert abs(info["resPrim"] - io["resPrim"]) <= tol * max(1.0, io["resPrim"])
+            assert abs(info["resDual"] - io["resDual"]) <= 10 * tol * max(1.0, io["resDual"])
+        x = np.zeros(n); info = {}
+        flag = prob.solve(x, numIterations=20000, ϵAbs=1e-7 if dtype == "f64" else 1e-4, ϵRel=1e-7 if dtype == "f64" else 1e-4, ρ=0.1, adptΡ=True, info=info)
+        xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-7 if dtype == "f64" else 1e-4, epsRel=1e-7 if dtype == "f64" else 1e-4, rho=0.1, adptRho=True)
+        assert rel(x, xo) <= (1e-6 if dtype == "f64" else 5e-3)
+        if dtype == "f64":
+            assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+
+
 KNOBS = [{"QPS_GRAPH": "0"}, {"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
          {"QPS_SMALL_REG": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"}]
 
