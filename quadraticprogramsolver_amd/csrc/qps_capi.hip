@@ -11,6 +11,33 @@
 using namespace qps;
 
 namespace qps {
+namespace {
+constexpr size_t kPinnedBytes = 512, kRecycleBlockMax = (size_t)512 << 20;   // blocks above 512 MiB go back to the driver (at most 4 x that per device stay cached, of 288 GB)
+constexpr int kMaxDevices = 64, kRecyclePerDevice = 4;
+std::mutex g_res_mu;
+std::vector<HandleResources> g_res[kMaxDevices];
+}  // namespace
+HandleResources acquire_resources(int device, size_t block_need) {
+    HandleResources r;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (device >= 0 && device < kMaxDevices && !g_res[device].empty()) { r = g_res[device].back(); g_res[device].pop_back(); }
+    }
+    if (!r.st) HIPC(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
+    if (!r.pinned) HIPC(hipHostMalloc(&r.pinned, kPinnedBytes));
+    if (r.block && (r.block_bytes < block_need || r.block_bytes > 4 * block_need + ((size_t)1 << 20))) { (void)hipFree(r.block); r.block = nullptr; r.block_bytes = 0; }
+    return r;
+}
+void recycle_resources(int device, HandleResources r) {
+    if (r.block && r.block_bytes > kRecycleBlockMax) { (void)hipFree(r.block); r.block = nullptr; r.block_bytes = 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (device >= 0 && device < kMaxDevices && (int)g_res[device].size() < kRecyclePerDevice) { g_res[device].push_back(r); return; }
+    }
+    if (r.block) (void)hipFree(r.block);
+    if (r.pinned) (void)hipHostFree(r.pinned);
+    if (r.st) (void)hipStreamDestroy(r.st);
+}
 thread_local LaunchTiming g_launch_timing;
 ProfLaunchScope::ProfLaunchScope(Profiler& pr, int c, int lvl) : p(pr), cat(c), a(nullptr), b(nullptr), active(pr.on(lvl)) {
     if (active) { a = p.get(); b = p.get(); g_launch_timing.start = a; g_launch_timing.stop = b; }
@@ -45,6 +72,7 @@ template <typename T> struct DenseSolver : SolverBase {
     T *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr, *xx = nullptr, *zz = nullptr, *tt = nullptr, *yv = nullptr;
     T *part = nullptr, *part2 = nullptr, *sw_part = nullptr, *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
     T* At = nullptr; void* small_out = nullptr; void* small_out_host = nullptr; bool small_ok = false;   // small-problem path
+    Arena arena; HandleResources res; double* stage_mat = nullptr; int64_t stage_mat_count = 0;
     int pass_slabs = 0, pass_rpw = 0;   // fused-pass plan (0 slabs: shape not supported, unfused loop only)
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
@@ -82,31 +110,39 @@ template <typename T> struct DenseSolver : SolverBase {
     DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
         device = dev; n = n_; m = m_; dtype = dt;
         HIPC(hipSetDevice(device));
-        HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        prof.st = st;
         NP = roundup(n, 64); MP = roundup(m, 64);
         const int64_t nn = (int64_t)NP * NP;
-        A = dalloc<T>((int64_t)MP * NP); P = dalloc<T>(nn); q = dalloc<T>(NP); l = dalloc<T>(MP); u = dalloc<T>(MP);
-        PI = dalloc<T>(nn); AA = dalloc<T>(nn); M = dalloc<T>(nn); S = dalloc<T>(nn); tmp = dalloc<T>(nn);
-        dinv = dalloc<T>((int64_t)(NP / 64) * 4096); fail = dalloc<int>(4);
-        x = dalloc<T>(NP); xp = dalloc<T>(NP); xx = dalloc<T>(NP); tt = dalloc<T>(NP); yv = dalloc<T>(NP);
-        z = dalloc<T>(MP); zp = dalloc<T>(MP); y = dalloc<T>(MP); zz = dalloc<T>(MP);
         part_tiles = gemv_cols_tiles(MP);
         pass_slabs = apass_plan<T>(NP, MP, &pass_rpw);
         const int slabs = std::max(std::max(part_tiles, pass_slabs), 1);
-        part = dalloc<T>((int64_t)slabs * NP);
-        part2 = dalloc<T>((int64_t)slabs * NP);
-        sw_part = dalloc<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
-        Ax = dalloc<T>(MP); Px = dalloc<T>(NP); Aty = dalloc<T>(NP);
-        scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
-        HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
-        stage = dalloc<double>((int64_t)NP + 2 * (int64_t)MP + 64);
         small_ok = admm_small_supported<T>((int)n, (int)m, NP, MP);
-        if (small_ok) {
-            At = dalloc<T>((int64_t)NP * MP);
-            small_out = dalloc<double>(32);
-            HIPC(hipHostMalloc(&small_out_host, 256));
-        }
+        // staging area of the matrix import (column-major doubles): inside the arena when the matrices are small
+        stage_mat_count = std::max((int64_t)n * n, (int64_t)m * n);
+        if (stage_mat_count > ((int64_t)1 << 20)) stage_mat_count = 0;
+        auto layout = [&](Arena& ar) {
+            A = ar.take<T>((int64_t)MP * NP); P = ar.take<T>(nn); q = ar.take<T>(NP); l = ar.take<T>(MP); u = ar.take<T>(MP);
+            PI = ar.take<T>(nn); AA = ar.take<T>(nn); M = ar.take<T>(nn); S = ar.take<T>(nn); tmp = ar.take<T>(nn);
+            dinv = ar.take<T>((int64_t)(NP / 64) * 4096); fail = ar.take<int>(4);
+            x = ar.take<T>(NP); xp = ar.take<T>(NP); xx = ar.take<T>(NP); tt = ar.take<T>(NP); yv = ar.take<T>(NP);
+            z = ar.take<T>(MP); zp = ar.take<T>(MP); y = ar.take<T>(MP); zz = ar.take<T>(MP);
+            part = ar.take<T>((int64_t)slabs * NP);
+            part2 = ar.take<T>((int64_t)slabs * NP);
+            sw_part = ar.take<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
+            Ax = ar.take<T>(MP); Px = ar.take<T>(NP); Aty = ar.take<T>(NP);
+            scratch = ar.take<unsigned long long>(16); res_dev = ar.take<double>(16);
+            stage = ar.take<double>((int64_t)NP + 2 * (int64_t)MP + 64);
+            if (small_ok) { At = ar.take<T>((int64_t)NP * MP); small_out = ar.take<double>(32); }
+            if (stage_mat_count > 0) stage_mat = ar.take<double>(stage_mat_count);
+        };
+        layout(arena);
+        res = acquire_resources(device, arena.planned());                    // stream, pinned block and maybe a recycled device block
+        st = res.st; prof.st = st;
+        try { arena.commit(res.block, res.block_bytes); }
+        catch (...) { recycle_resources(device, res); res = HandleResources(); st = nullptr; prof.st = nullptr; throw; }
+        res.block = nullptr;                                                  // owned by the arena from here on
+        layout(arena);
+        res_host = reinterpret_cast<double*>(res.pinned);                     // one pinned block: check results | small-kernel report
+        small_out_host = small_ok ? reinterpret_cast<char*>(res.pinned) + 16 * sizeof(double) : nullptr;
         const double s = sizeof(T);
         // algorithmic bytes per launch (SURVEY §8d "per-kernel algorithmic bytes")
         cat_atw = prof.category("gemv_cols(A'w)", s * ((double)m * n + m + n));
@@ -128,11 +164,9 @@ template <typename T> struct DenseSolver : SolverBase {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
         drop_graphs();
-        void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, fail, x, xp, z, zp, y, xx, zz, tt, yv, part, part2, sw_part, Ax, Px, Aty, scratch, res_dev, stage, At, small_out};
-        for (void* p : ptrs) if (p) (void)hipFree(p);
-        if (res_host) (void)hipHostFree(res_host);
-        if (small_out_host) (void)hipHostFree(small_out_host);
-        if (st) (void)hipStreamDestroy(st);
+        prof.release_events();
+        res.block = arena.base; res.block_bytes = arena.bytes; arena.base = nullptr;
+        if (res.st) recycle_resources(device, res); else arena.release();
     }
 
     // host double array -> device T vector (zero padded allocation is preserved beyond `count`)
@@ -151,6 +185,12 @@ template <typename T> struct DenseSolver : SolverBase {
     // column-major host matrix -> row-major device T (streamed through a bounded staging buffer, column panels)
     void upload_matrix(const double* h, int64_t ldh, int rows, int cols, T* d, int64_t ldd) {
         if (rows <= 0 || cols <= 0) return;
+        if (stage_mat && (int64_t)rows * cols <= stage_mat_count) {   // small matrix: one copy through the arena's staging area
+            HIPC(hipMemcpy2DAsync(stage_mat, sizeof(double) * (size_t)rows, h, sizeof(double) * (size_t)ldh, sizeof(double) * (size_t)rows, (size_t)cols, hipMemcpyHostToDevice, st));
+            import_colmajor<T>(st, stage_mat, rows, rows, cols, d, ldd);
+            HIPC(hipStreamSynchronize(st));
+            return;
+        }
         const int64_t budget = (int64_t)32 << 20;   // doubles per panel (256 MiB)
         int pc = (int)std::max<int64_t>(64, (budget / std::max(rows, 1)) / 64 * 64);
         double* buf = nullptr;

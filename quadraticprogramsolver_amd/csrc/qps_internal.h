@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,11 @@ struct Profiler {
         pending.clear();
     }
     void reset() { for (auto& s : stats) { s.seconds = 0; s.launches = 0; } }
+    void release_events() {   // the stream may outlive this profiler (recycled): leave no event behind on it
+        for (auto e : pool) (void)hipEventDestroy(e);
+        for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        pool.clear(); pending.clear();
+    }
     ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } }
 };
 // Times ONE kernel dispatch by its own timestamps: the launcher called inside the scope consumes g_launch_timing (qps_kernels.h).
@@ -80,6 +86,38 @@ template <typename T> inline T* dalloc(int64_t count) {
     HIPC(hipStreamSynchronize(nullptr));
     return p;
 }
+
+// One device allocation per handle: thirty-odd hipMalloc + zero-fill + hipFree calls cost ~4.5 ms per handle, ten times the
+// solve itself at the reference's test sizes.  Lay the buffers out twice: once against a null base to add up the sizes, once for real.
+struct Arena {
+    char* base = nullptr; size_t off = 0; bool planning = true;
+    template <typename T> T* take(int64_t count) {
+        if (count < 64) count = 64;
+        off = (off + 255) & ~(size_t)255;
+        T* p = planning ? nullptr : reinterpret_cast<T*>(base + off);
+        off += sizeof(T) * (size_t)count;
+        return p;
+    }
+    size_t bytes = 0;
+    size_t planned() const { return ((off + 255) & ~(size_t)255) + 256; }
+    // allocate what the planning pass added up (or adopt a recycled block of at least that size), zero it, restart the layout for real
+    void commit(char* recycled = nullptr, size_t recycled_bytes = 0) {
+        const size_t need = planned();
+        if (recycled) { base = recycled; bytes = recycled_bytes; }
+        else { HIPC(hipMalloc((void**)&base, need)); bytes = need; }
+        HIPC(hipMemset(base, 0, need));
+        HIPC(hipStreamSynchronize(nullptr));   // the fill runs on the null stream; the solver streams are not ordered against it
+        off = 0; planning = false;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; }
+};
+
+// Per-device recycling of what a dense handle needs besides its data: the stream, the pinned read-back block and (for small
+// problems) the device block itself.  hipStreamCreate / hipHostMalloc / hipMalloc and their counterparts cost ~3 ms per handle --
+// five times a whole solve at the reference's test sizes, where every SolveQuadraticProgram! call builds and drops a handle.
+struct HandleResources { hipStream_t st = nullptr; void* pinned = nullptr; char* block = nullptr; size_t block_bytes = 0; };
+HandleResources acquire_resources(int device, size_t block_need);      // block may come back null (caller allocates)
+void recycle_resources(int device, HandleResources r);                  // stream must be idle
 
 struct SolverBase {
     int device = 0; hipStream_t st = nullptr; int dtype = 0; int64_t n = 0, m = 0; bool sparse = false;
