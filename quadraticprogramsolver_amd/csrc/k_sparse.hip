@@ -351,6 +351,7 @@ struct Csr {
 };
 
 template <typename T> struct SparseSolver : SolverBase {
+    HandleResources res;
     Csr A, At, P, PA;   // PA = [P; A] stacked, column-blocked only: P u and A u of the CG operator from ONE pass over u
     T *q = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr;
     T *xx = nullptr, *zz = nullptr, *w = nullptr, *tt = nullptr, *cu = nullptr, *cu2 = nullptr, *cr = nullptr, *cc = nullptr, *tm = nullptr;
@@ -459,7 +460,8 @@ template <typename T> struct SparseSolver : SolverBase {
                  const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* qh, const double* lh, const double* uh, int base) {
         device = dev; n = n_; m = m_; dtype = dt; sparse = true;
         HIPC(hipSetDevice(device));
-        HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        res = acquire_resources(device, 0);   // recycled stream + pinned block (qps_internal.h)
+        st = res.st;
         prof.st = st;
         const int64_t pnnz = Pcp[n] - base, annz = Acp[n] - base;
         if (pnnz > 2000000000LL || annz > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 non-zeros");
@@ -497,9 +499,9 @@ template <typename T> struct SparseSolver : SolverBase {
         nb_n = (int)((n + 255) / 256);
         part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n) + 64); part_rr = dalloc<double>(nb_n + 64);
         state = reinterpret_cast<CgState*>(dalloc<double>(16));
-        HIPC(hipHostMalloc((void**)&state_host, sizeof(CgState)));
+        state_host = reinterpret_cast<CgState*>(res.pinned);                          // pinned block: CG state | check results
         scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
-        HIPC(hipHostMalloc((void**)&res_host, 16 * sizeof(double)));
+        res_host = reinterpret_cast<double*>(reinterpret_cast<char*>(res.pinned) + 128);
         stage = dalloc<double>(std::max(nn, mm) + 64);
         upload_vec(qh, q, n); upload_vec(lh, l, m); upload_vec(uh, u, m);
         const double s = sizeof(T);
@@ -523,9 +525,8 @@ template <typename T> struct SparseSolver : SolverBase {
         void* ptrs[] = {A.rp, A.ci, A.va, A.rb, At.rp, At.ci, At.va, At.rb, P.rp, P.ci, P.va, P.rb, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
                         Ax, Px, Aty, part_uc, part_rr, state, scratch, res_dev, stage};
         for (void* p : ptrs) if (p) (void)hipFree(p);
-        if (res_host) (void)hipHostFree(res_host);
-        if (state_host) (void)hipHostFree(state_host);
-        if (st) (void)hipStreamDestroy(st);
+        prof.release_events();
+        if (res.st) recycle_resources(device, res);
     }
 
     void spmv(const Csr& M, const T* xin, T* out, T a, const T* v0, T b0, const T* v1, T b1, const CgState* stt,

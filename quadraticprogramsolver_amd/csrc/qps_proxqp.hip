@@ -90,7 +90,7 @@ template <typename T> __global__ void k_pq_lower(int NP, const T* __restrict__ s
 inline dim3 g1(int n) { return dim3((unsigned)((std::max(n, 1) + 255) / 256)); }
 
 template <typename T> struct ProxQpSolver : ProxQpBase {
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr; HandleResources res;
     int NP = 0, MP = 0, MEP = 0, mtot = 0, nb = 0, part_tiles = 0;
     T *G = nullptr, *Aonly = nullptr, *P = nullptr, *q = nullptr, *g = nullptr, *dual = nullptr, *slack = nullptr, *x = nullptr;
     T *w = nullptr, *v = nullptr, *de = nullptr, *di = nullptr, *tt = nullptr, *yv = nullptr, *xx = nullptr, *part = nullptr, *sw_part = nullptr;
@@ -101,7 +101,8 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
     ProxQpSolver(int dev, int64_t n_, int64_t me_, int64_t mi_) {
         device = dev; n = n_; me = me_; mi = mi_;
         HIPC(hipSetDevice(device));
-        HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        res = acquire_resources(device, 0);   // recycled stream + pinned block (qps_internal.h)
+        st = res.st;
         mtot = (int)(me + mi);
         NP = roundup(n, 64); MP = roundup(mtot, 64); MEP = roundup(std::max<int64_t>(me, 1), 64);
         const int64_t nn = (int64_t)NP * NP;
@@ -113,7 +114,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         sw_part = dalloc<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
         PI = dalloc<T>(nn); KK = dalloc<T>(nn); M = dalloc<T>(nn); S = dalloc<T>(nn); tmp = dalloc<T>(nn); dinv = dalloc<T>((int64_t)(NP / 64) * 4096);
         fail = dalloc<int>(4); slots = dalloc<unsigned long long>(16);
-        HIPC(hipHostMalloc((void**)&slots_host, 16 * sizeof(unsigned long long)));
+        slots_host = reinterpret_cast<unsigned long long*>(res.pinned);
         stage = dalloc<double>(std::max<int64_t>((int64_t)MP * NP, nn) + 64);
     }
     ~ProxQpSolver() override {
@@ -121,8 +122,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         if (st) (void)hipStreamSynchronize(st);
         void* ptrs[] = {G, Aonly, P, q, g, dual, slack, x, w, v, de, di, tt, yv, xx, part, sw_part, PI, KK, M, S, tmp, dinv, X1, X2, X3, fail, slots, stage};
         for (void* p_ : ptrs) if (p_) (void)hipFree(p_);
-        if (slots_host) (void)hipHostFree(slots_host);
-        if (st) (void)hipStreamDestroy(st);
+        if (res.st) recycle_resources(device, res);
     }
     void put_vec(const double* h, T* d, int64_t c) {
         if (c <= 0) return;
