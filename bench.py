@@ -235,7 +235,7 @@ def cpu_baseline(P, q, A, l, u, config):
     x, i_all = co.solve(P, q, A, l, u, numIterations=50, epsAbs=0.0, epsRel=0.0, numThreads=cores)
     x, i_one = co.solve(P, q, A, l, u, numIterations=10, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1)
     return {"value": round(50 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": "same C2 problem: full setup + 50 ADMM iterations on all cores (OpenMP over rows); "
+            "sample": "same problem as the GPU run: full setup + 50 ADMM iterations on all cores (OpenMP over rows); "
                       "single-thread loop rate from 10 more iterations",
             "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(10 / i_one["tLoop"], 3),
             "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
