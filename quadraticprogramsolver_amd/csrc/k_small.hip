@@ -210,10 +210,10 @@ __global__ __launch_bounds__(ST) void k_admm_small(SmallArgs a, const T* __restr
 //   s[r]     = S[g + 8 r][lane]           y = W t:  rows j = g + 8 r <= lane (upper part = W');  x~ = W' y: rows >= lane (lower part = W)
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int NB, int MB>      // NB = n padded / 64 (1 or 2), MB = m padded / 64
-__global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __restrict__ A, const T* __restrict__ P, const T* __restrict__ S,
-                                                        const T* __restrict__ q, const T* __restrict__ l, const T* __restrict__ u,
-                                                        T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz, T* __restrict__ gy,
-                                                        SmallOut* __restrict__ out) {
+__device__ __forceinline__ void small_reg_body(const SmallArgs& a, const T* __restrict__ A, const T* __restrict__ P, const T* __restrict__ S,
+                                               const T* __restrict__ q, const T* __restrict__ l, const T* __restrict__ u,
+                                               T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz, T* __restrict__ gy,
+                                               SmallOut* __restrict__ out) {
     constexpr int NPc = 64 * NB, RA = 8 * MB, RS = 8 * NB;          // rows of A / S per wave
     __shared__ T scrN[2][8][NPc];
     __shared__ T scrM[8][64 * MB];
@@ -430,6 +430,28 @@ __global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __
     }
 }
 
+template <typename T, int NB, int MB>
+__global__ __launch_bounds__(512) void k_admm_small_reg(SmallArgs a, const T* __restrict__ A, const T* __restrict__ P, const T* __restrict__ S,
+                                                        const T* __restrict__ q, const T* __restrict__ l, const T* __restrict__ u,
+                                                        T* __restrict__ gx, T* __restrict__ gxp, T* __restrict__ gz, T* __restrict__ gy,
+                                                        SmallOut* __restrict__ out) {
+    small_reg_body<T, NB, MB>(a, A, P, S, q, l, u, gx, gxp, gz, gy, out);
+}
+// batch of independent QPs of one shape: workgroup b runs QP b with its own arguments (iteration window, rho, ...); a QP whose
+// window is empty (finished, or waiting for nothing) returns at once.  Matrices NP*NP / MP*NP apart, vectors NP / MP apart.
+template <typename T, int NB, int MB>
+__global__ __launch_bounds__(512) void k_admm_small_reg_batch(const SmallArgs* __restrict__ args, const T* __restrict__ A, const T* __restrict__ P,
+                                                              const T* __restrict__ S, const T* __restrict__ q, const T* __restrict__ l,
+                                                              const T* __restrict__ u, T* __restrict__ gx, T* __restrict__ gxp,
+                                                              T* __restrict__ gz, T* __restrict__ gy, SmallOut* __restrict__ out) {
+    const int64_t b = blockIdx.x;
+    const SmallArgs a = args[b];
+    if (a.it_begin >= a.it_end) return;
+    constexpr int64_t NPc = 64 * NB, MPc = 64 * MB;
+    small_reg_body<T, NB, MB>(a, A + b * MPc * NPc, P + b * NPc * NPc, S + b * NPc * NPc, q + b * NPc, l + b * MPc, u + b * MPc,
+                              gx + b * NPc, gxp + b * NPc, gz + b * MPc, gy + b * MPc, out + b);
+}
+
 // At[c][r] = A[r][c]  (A row-major MP x NP, At row-major NP x MP); sizes are small here
 template <typename T> __global__ void k_transpose_small(const T* __restrict__ A, int NP, int MP, T* __restrict__ At) {
     const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
@@ -497,6 +519,31 @@ template <typename T> void transpose_small(hipStream_t st, const T* A, int NP, i
     hipLaunchKernelGGL((k_transpose_small<T>), dim3((MP + 255) / 256, NP), dim3(256), 0, st, A, NP, MP, At);
 }
 
+template <typename T> bool admm_small_batch_supported(int NP, int MP) {
+    static const int reg_env = [] { const char* e = getenv("QPS_SMALL_REG"); return e ? atoi(e) : 1; }();
+    return reg_env && MP >= 64 && (NP == 64 || NP == 128) && MP / 64 <= (sizeof(T) == 8 ? 2 : 4);
+}
+size_t admm_small_args_bytes() { return sizeof(SmallArgs); }
+void admm_small_args_set(void* host_array, int idx, int n, int m, int NP, int MP, int it_begin, int it_end, int numItrConv, int adptRho, double rho,
+                         double rhorho, double sigma, double alpha, double epsAbs, double epsRel, double epsAdmm, double fctrRho) {
+    reinterpret_cast<SmallArgs*>(host_array)[idx] = SmallArgs{n, m, NP, MP, it_begin, it_end, numItrConv, adptRho, rho, rhorho, sigma, alpha, epsAbs, epsRel, epsAdmm, fctrRho};
+}
+template <typename T>
+void admm_small_batch(hipStream_t st, int count, int NP, int MP, const void* args_dev, const T* A, const T* P, const T* S, const T* q, const T* l,
+                      const T* u, T* x, T* xp, T* z, T* y, void* outs_dev) {
+    const SmallArgs* a = reinterpret_cast<const SmallArgs*>(args_dev);
+    SmallOut* o = reinterpret_cast<SmallOut*>(outs_dev);
+    const int mb = MP / 64;
+#define QPS_REGB(NBv, MBv) hipLaunchKernelGGL((k_admm_small_reg_batch<T, NBv, MBv>), dim3(count), dim3(512), 0, st, a, A, P, S, q, l, u, x, xp, z, y, o)
+    if (NP == 64) {
+        if (mb == 1) QPS_REGB(1, 1); else if (mb == 2) QPS_REGB(1, 2);
+        else if constexpr (sizeof(T) == 4) { if (mb == 3) QPS_REGB(1, 3); else QPS_REGB(1, 4); }
+    } else {
+        if (mb == 1) QPS_REGB(2, 1); else if (mb == 2) QPS_REGB(2, 2);
+        else if constexpr (sizeof(T) == 4) { if (mb == 3) QPS_REGB(2, 3); else QPS_REGB(2, 4); }
+    }
+#undef QPS_REGB
+}
 size_t admm_small_out_bytes() { return sizeof(SmallOut); }
 void admm_small_read(const void* host_copy, int* last_it, int* convFlag, int* need_rho, double* res8) {
     const SmallOut* o = reinterpret_cast<const SmallOut*>(host_copy);
@@ -505,6 +552,8 @@ void admm_small_read(const void* host_copy, int* last_it, int* convFlag, int* ne
 }
 
 #define INST(T)                                                                                                                    \
+    template bool admm_small_batch_supported<T>(int, int);                                                                         \
+    template void admm_small_batch<T>(hipStream_t, int, int, int, const void*, const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*, void*); \
     template void transpose_small<T>(hipStream_t, const T*, int, int, T*);                                                         \
     template bool admm_small_supported<T>(int, int, int, int);                                                                     \
     template void admm_small<T>(hipStream_t, int, int, int, int, int, int, int, int, double, double, double, double, double, double, \

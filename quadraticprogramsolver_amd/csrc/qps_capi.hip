@@ -472,6 +472,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     int* h_int = nullptr; double* h_dbl = nullptr;   // pinned staging for the small per-QP arrays
     bool have_AA = false; double fac_sigma = -1; int fac_nb = -1; std::vector<double> fac_rho;   // per-QP factor cache
+    char* sb_args = nullptr; void* sb_host = nullptr;                                              // small-batch path: argument / report slots
 
     BatchedDenseSolver(int dev, int cnt, int64_t n_, int64_t m_) {
         device = dev; n = n_; m = m_; count = cnt;
@@ -504,6 +505,8 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         if (res_host) (void)hipHostFree(res_host);
         if (h_int) (void)hipHostFree(h_int);
         if (h_dbl) (void)hipHostFree(h_dbl);
+        if (sb_args) (void)hipFree(sb_args);
+        if (sb_host) (void)hipHostFree(sb_host);
         if (st) (void)hipStreamDestroy(st);
     }
     void put_vec(const double* h, T* d, int64_t cnt_) {
@@ -596,6 +599,46 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         PassBatch pb; pb.count = count; pb.slabs = slabs; pb.rho_arr = d_rho; pb.active = d_active;
         int rhs_slabs = 0, nactive = count, ii = 0;
         const int nblk = (NP + nb - 1) / nb;
+        if (p.loopVariant == 0 && nblk == 1 && admm_small_batch_supported<T>(NP, MP)) {
+            // Small shapes: ONE workgroup per QP runs that QP's whole loop (register-resident kernel, k_small.hip); the host only
+            // steps in when some QP wants a rho switch (refactor, relaunch from its own iteration) -- SolveQuadraticProgram.jl:45-71 per QP.
+            const size_t ab = admm_small_args_bytes(), ob = admm_small_out_bytes();
+            if (!sb_args) { sb_args = dalloc<char>((int64_t)(ab + ob) * count + 64); HIPC(hipHostMalloc(&sb_host, (ab + ob) * (size_t)count + 64)); }
+            char* args_h = static_cast<char*>(sb_host); char* outs_h = args_h + ab * count;
+            char* args_d = sb_args; char* outs_d = sb_args + ab * count;
+            std::vector<int> it(count, 0);
+            HIPC(hipMemsetAsync(xp, 0, sizeof(T) * (size_t)count * NP, st));                        // :38
+            while (nactive > 0) {
+                for (int b = 0; b < count; ++b)
+                    admm_small_args_set(args_h, b, (int)n, (int)m, NP, MP, it[b], active[b] ? p.numIterations : it[b], p.numItrConv, p.adptRho, rho[b], rhorho[b],
+                                        sigma, alpha, p.epsAbs, p.epsRel, epsAdmm, p.fctrRho);
+                HIPC(hipMemcpyAsync(args_d, args_h, ab * count, hipMemcpyHostToDevice, st));
+                admm_small_batch<T>(st, count, NP, MP, args_d, A, P, S, q, l, u, x, xp, z, y, outs_d);
+                HIPC(hipMemcpyAsync(outs_h, outs_d, ob * count, hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                std::vector<int> changed;
+                for (int b = 0; b < count; ++b) {
+                    if (!active[b]) continue;
+                    int last = 0, flag = QPS_CONV_NUM_ITR, need = 0; double r8[8];
+                    admm_small_read(outs_h + ob * b, &last, &flag, &need, r8);
+                    it[b] = last; rhorho[b] = r8[4];
+                    if (!std::isnan(r8[0]) || !std::isnan(r8[1])) { resP[b] = r8[0]; resD[b] = r8[1]; }
+                    if (flag != QPS_CONV_NUM_ITR) { conv[b] = flag; iters[b] = last; active[b] = 0; --nactive; }   // :66-68
+                    else if (need && last < p.numIterations) { rho[b] = rhorho[b]; ++nref[b]; changed.push_back(b); }   // :47-51
+                    else { iters[b] = p.numIterations; active[b] = 0; --nactive; }
+                }
+                if (!changed.empty()) {
+                    const double ta = now_s();
+                    const bool together = (int)changed.size() * 2 >= count;
+                    if (together) { push_state(rho, rhorho, active); factorize_all(0.0, sigma, false, d_rho); for (int b = 0; b < count; ++b) fac_rho[b] = rho[b]; }
+                    else for (int b : changed) { factorize_one(b, rho[b], sigma, false); fac_rho[b] = rho[b]; }
+                    if (together) check_fail(all); else check_fail(changed);
+                    const double dt = (now_s() - ta) / changed.size();
+                    for (int b : changed) tref[b] += dt;
+                }
+            }
+            HIPC(hipMemcpyAsync(xres, x, sizeof(T) * (size_t)count * NP, hipMemcpyDeviceToDevice, st));
+        }
         for (ii = 1; ii <= p.numIterations && nactive > 0; ++ii) {                                  // :45
             std::vector<int> changed;
             if (p.adptRho)

@@ -99,6 +99,15 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
 // ---- small-problem path (k_small.hip): the whole loop in one single-workgroup launch ---------------------------------------
 template <typename T> bool admm_small_supported(int n, int m, int NP, int MP);
 template <typename T> void transpose_small(hipStream_t st, const T* A, int NP, int MP, T* At);
+// batch of small QPs, one workgroup per QP (register-resident kernel): per-QP argument slots are filled on the host with
+// admm_small_args_set (an empty iteration window parks a QP), reports come back as admm_small_out_bytes() records
+template <typename T> bool admm_small_batch_supported(int NP, int MP);
+size_t admm_small_args_bytes();
+void admm_small_args_set(void* host_array, int idx, int n, int m, int NP, int MP, int it_begin, int it_end, int numItrConv, int adptRho, double rho,
+                         double rhorho, double sigma, double alpha, double epsAbs, double epsRel, double epsAdmm, double fctrRho);
+template <typename T>
+void admm_small_batch(hipStream_t st, int count, int NP, int MP, const void* args_dev, const T* A, const T* P, const T* S, const T* q, const T* l,
+                      const T* u, T* x, T* xp, T* z, T* y, void* outs_dev);
 // runs iterations it_begin+1 .. it_end (or until a termination test fires / the proposed rho leaves the fctrRho band);
 // out_dev receives {last iteration, convFlag, need_rho, res[8]} (admm_small_out_bytes / admm_small_read)
 template <typename T>

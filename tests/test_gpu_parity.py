@@ -228,6 +228,33 @@ def test_batch_api(gpu, c_oracle):
             assert np.abs(X[b] - np.linalg.solve(free[b][0], -free[b][1])).max() <= 1e-6
 
 
+@pytest.mark.parametrize("n,m,dtype", [(60, 100, "f64"), (100, 60, "f64"), (64, 250, "f32")])
+def test_small_batch_one_workgroup_per_qp(gpu, c_oracle, n, m, dtype):
+    """Batches of small QPs take the register-resident kernel with one workgroup per QP (each QP runs its own loop; the host only
+    refactors on rho switches): fixed-K iterates, and with adaptive rho the per-QP flags, stopping iterations and refactor counts,
+    must equal independent runs of the oracle."""
+    cnt = 9
+    probs = [GenerateDenseBenchmarkQP(n, m, stream=30 + b, feasible=(b != 4)) for b in range(cnt)]   # QP 4: infeasible draw (stalls)
+    tol = 1e-9 if dtype == "f64" else 2e-3
+    with gpu.QuadraticProgramBatch(probs, dtype=dtype) as batch:
+        X, flags, infos = batch.solve(numIterations=60, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
+        for b in range(cnt):
+            xo, io = c_oracle.solve(*probs[b], numIterations=60, epsAbs=0.0, epsRel=0.0, rho=0.1)
+            assert rel(X[b], xo) <= tol and infos[b]["iterations"] == 60 and int(flags[b]) == 1
+            assert abs(infos[b]["resPrim"] - io["resPrim"]) <= tol * max(1.0, io["resPrim"])
+        eps = 1e-7 if dtype == "f64" else 1e-4
+        X, flags, infos = batch.solve(numIterations=4000, ϵAbs=eps, ϵRel=eps, ρ=0.1, adptΡ=True)
+        its = set()
+        for b in range(cnt):
+            xo, io = c_oracle.solve(*probs[b], numIterations=4000, epsAbs=eps, epsRel=eps, rho=0.1, adptRho=True)
+            assert np.abs(X[b] - xo).max() <= (ABS_DEV_THR if dtype == "f64" else 5e-3)
+            if dtype == "f64":
+                assert int(flags[b]) == io["convFlag"] and infos[b]["iterations"] == io["iterations"], (b, infos[b], io["iterations"])
+                assert infos[b]["numRefactor"] == io["numRefactor"]
+            its.add(infos[b]["iterations"])
+        assert min(its) >= 25
+
+
 def test_full_size_properties_c2(gpu):
     """BASELINE config 2 (n = 4096, m = 8192, fp64) through size-independent properties: the linear solve satisfies
     (P + σI + ρA'A) x~ = σx − q + A'(ρz − y) and z~ = A x~ to fp64 accuracy, the reported residuals are the true ones,

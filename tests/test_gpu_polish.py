@@ -164,7 +164,7 @@ def test_batch_polish_equals_single_problem_polish(gpu):
     for (P, q, A, l, u) in probs:
         with gpu.QuadraticProgram(P, q, A, l, u) as prob:
             x = np.zeros(n); info = {}
-            prob.solve(x, info=info, polish=True, loopVariant=2, **kw)
+            prob.solve(x, info=info, polish=True, **kw)   # same kernel as the batch takes for this shape: the sign noise of y on inactive rows decides the active set
             singles.append((x, info))
     with gpu.QuadraticProgramBatch(probs) as batch:
         X, flags, infos = batch.solve(polish=True, **kw)
