@@ -30,6 +30,31 @@ CONFIGS = {
 }
 
 
+def spawn_ranks_if_needed(args, argv):
+    """`python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed.run on 127.0.0.1) when it was
+    not launched under torchrun.  Runs BEFORE torch or the HIP library is imported: a process that has touched the GPU is never
+    re-executed; the ranks are children and this process only waits and exits with their code.  Rank 0's JSON line reaches stdout
+    through the inherited descriptor."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: launch N ranks for --gpus N")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,22 +67,30 @@ def main():
     ap.add_argument("--no-time-to-eps", action="store_true")
     ap.add_argument("--profile-level", type=int, default=1,
                     help="1: HIP-event bracket the dominant kernel on every 50th iteration; 2: every launch of every kernel")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="rank plumbing only (rendezvous, barrier, timing reduction) with a sleep in place of the solver: runs without a GPU")
     args = ap.parse_args()
+    spawn_ranks_if_needed(args, sys.argv[1:])
 
     import torch  # first: keeps a single HIP runtime in the process (torch bundles its own libamdhip64)
     import numpy as np
-    import quadraticprogramsolver_amd as qps
     from quadraticprogramsolver_amd import dist as qd
 
     info = qd.rank_info_from_env()
-    if info.world_size != args.gpus and info.world_size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}")
-    backend = qd.init_process_group(info)
+    if info.world_size != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={info.world_size}")
+    ndev = torch.cuda.device_count()       # does not initialise the GPU
+    # one rank per GPU -> the barrier and the timing reduction go through RCCL (backend "nccl"); ranks that have to share a card
+    # (more ranks than devices, e.g. a rehearsal on a 1-GPU box) or a CPU-only selftest use gloo
+    backend = qd.init_process_group(info, prefer=os.environ.get("QPS_DIST_BACKEND") or ("nccl" if ndev >= info.world_size and ndev > 0 else "gloo"))
+    device = info.local_rank % ndev if ndev > 0 else 0
+    if args.launcher_selftest:
+        return launcher_selftest(args, info, backend, device, ndev, qd)
+    import quadraticprogramsolver_amd as qps
     cfg = CONFIGS[args.config]
     n, m = cfg["n"], cfg["m"]
     s = 8 if cfg["dtype"] == "f64" else 4
 
-    device = info.local_rank if torch.cuda.device_count() > info.local_rank else 0
     if torch.cuda.is_available():
         torch.cuda.set_device(device)      # torch.cuda.synchronize() below must act on this rank's GPU, not on GPU 0
     if args.config in ("c3", "c4"):
@@ -143,10 +176,25 @@ def main():
     prob.close()
     if info.rank == 0:
         print(json.dumps(out), flush=True)
-    if info.world_size > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    qd.shutdown(info)
+
+
+def launcher_selftest(args, info, backend, device, ndev, qd):
+    """The N-rank plumbing without the solver (no GPU needed): every rank sleeps 1 ms per "step"; the line is marked as a selftest
+    and carries no throughput claim."""
+    qd.barrier(info)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    qd.barrier(info)
+    elapsed = time.perf_counter() - t0
+    value, tmax = qd.gather_timings(info, elapsed, float(args.steps))
+    (ranks,) = qd.all_sum(info, 1.0)
+    if info.rank == 0:
+        print(json.dumps({"metric": "launcher selftest (no solver call)", "value": None, "unit": None, "n_gpus": info.world_size, "steps": args.steps,
+                          "warmup": args.warmup, "selftest": True, "ranks_counted": int(ranks), "steps_counted": round(value * tmax),
+                          "config": {"dist_backend": backend, "devices_visible": ndev}}), flush=True)
+    qd.shutdown(info)
 
 
 def side_config(args, cfg, info, backend, device, qps, qd, np, torch):
@@ -203,10 +251,7 @@ def side_config(args, cfg, info, backend, device, qps, qd, np, torch):
             out["cg_iterations_per_admm_iteration"] = round(cg["n"] / (units_per_step * args.steps), 2)
         print(json.dumps(out), flush=True)
     solver.close()
-    if info.world_size > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    qd.shutdown(info)
 
 
 def pmc_traffic(kernel_label, dtype):

@@ -23,11 +23,6 @@ namespace qps {
 
 namespace {
 
-template <typename T> __device__ __forceinline__ T wsum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ unsigned long long absbits(double v) { return (unsigned long long)__double_as_longlong(fabs(v)); }
 __device__ __forceinline__ unsigned long long umax(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 

@@ -344,6 +344,10 @@ __device__ __forceinline__ void small_reg_body(const SmallArgs& a, const T* __re
         }
         if (it % a.numItrConv == 0) {                                                             // :63  CheckConvergence :79-112
             T Ax[MB], Px[NB], Aty[NB];
+            // av / atv / nsum read every wave's row of their scratch buffer after ONE barrier and have no trailing barrier: two
+            // consecutive uses of the SAME buffer need a barrier in between (scrN ping-pongs [0]/[1]; scrM was last read by
+            // av(xt, zt) above with only register work since) or a fast wave overwrites rows a slower wave is still summing
+            __syncthreads();
             av(x, Ax);
 #pragma unroll
             for (int c = 0; c < NB; ++c) p[c] = T(0);

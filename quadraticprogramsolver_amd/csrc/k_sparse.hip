@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int n, const T* __restrict__ b,
     d = block_sum_256(d, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = d;
 }
-__global__ __launch_bounds__(256) void k_cg_init_final(int nparts, const double* __restrict__ partial, CgState* st, double abstol, int maxiter) {
+__global__ __launch_bounds__(256) void k_cg_init_final(int nparts, const double* __restrict__ partial, CgState* st, double abstol, double reltol, int maxiter) {
     __shared__ double sh[4];
     double d = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) d += partial[i];
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_cg_init_final(int nparts, const double*
     if (threadIdx.x == 0) {
         const double residual = sqrt(d);
         st->res2 = d; st->prev2 = 1.0;
-        st->tol = fmax(1.4901161193847656e-08 * residual, abstol);   // reltol = sqrt(eps(Float64))
+        st->tol = fmax(reltol * residual, abstol);   // reltol = sqrt(eps(real(eltype(b)))): the handle's arithmetic type
         st->iters = 0; st->maxiter = maxiter;
         st->done = (!(residual <= st->tol) && 0 < maxiter) ? 0 : 1;
     }
@@ -575,7 +575,8 @@ template <typename T> struct SparseSolver : SolverBase {
         op_reduced(xx, cc, rho, sigma, nullptr, nullptr);
         T* ub[2] = {cu, cu2}; int ui = 0;                            // ub[ui] = current direction u
         hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_n), dim3(256), 0, st, (int)n, tt, cc, cr, ub[ui], part_rr);
-        hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur], eps_pcg, itr_pcg);
+        hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur], eps_pcg,
+                           sizeof(T) == 8 ? 1.4901161193847656e-08 : 3.4526698300124393e-04, itr_pcg);
         int launched = 0, batch = std::max(1, std::min(last_cg + 1, 64));
         for (;;) {
             for (int b = 0; b < batch; ++b) {

@@ -11,12 +11,6 @@ namespace qps {
 
 namespace {
 
-template <typename T> __device__ __forceinline__ T wsum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Both sweeps in ONE pass over the lower triangle (nb >= n, S lower = W = inv(L)):
 //     y_r = sum_{c<=r} W[r][c] t[c]            (forward sweep, row dot)

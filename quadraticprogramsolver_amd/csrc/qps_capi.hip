@@ -305,7 +305,7 @@ template <typename T> struct DenseSolver : SolverBase {
                 it = last; convFlag = flag; rhorho = r8[4];
                 if (!std::isnan(r8[0]) || !std::isnan(r8[1])) { resP = r8[0]; resD = r8[1]; }
                 if (flag != QPS_CONV_NUM_ITR) break;                                                // :66-68
-                if (need) {                                                                         // :47-51
+                if (need && it < p.numIterations) {                                                 // :47-51 (the loop top is never re-entered after the last iteration)
                     rho = rhorho; ++nref;
                     const double ta = now_s();
                     factorize(rho, sigma, false);
@@ -487,7 +487,11 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         q = dalloc<T>(c * NP); l = dalloc<T>(c * MP); u = dalloc<T>(c * MP);
         x = dalloc<T>(c * NP); xp = dalloc<T>(c * NP); xres = dalloc<T>(c * NP); xx = dalloc<T>(c * NP); tt = dalloc<T>(c * NP);
         yv = dalloc<T>(c * NP); Px = dalloc<T>(c * NP); Aty = dalloc<T>(c * NP); z = dalloc<T>(c * MP); y = dalloc<T>(c * MP);
-        part = dalloc<T>(c * slabs * NP); part2 = dalloc<T>(c * slabs * NP); part_tmp = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
+        // polishing (one QP at a time) writes the slabs of a count = 1 pass plan, or the tiles of the column GEMV, into `part`:
+        // count * slabs can be smaller than either (count = 3, NP = 2048: 246 < 256)
+        int rpw1 = 0;
+        const int64_t part_slabs = std::max<int64_t>(std::max<int64_t>(c * slabs, apass_plan<T>(NP, MP, &rpw1, 1)), std::max(part_tiles, 1));
+        part = dalloc<T>(part_slabs * NP); part2 = dalloc<T>(c * slabs * NP); part_tmp = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
         sw_slabs = sweep_fused_slabs<T>(NP, count); sw_part = dalloc<T>(c * std::max(sw_slabs, 1) * NP);
         fail = dalloc<int>(count + 4); d_active = dalloc<int>(count + 4); d_rho = dalloc<double>(count + 4); d_rhorho = dalloc<double>(count + 4);
         scratch = dalloc<unsigned long long>(16 * c); res_dev = dalloc<double>(8 * c);
@@ -755,6 +759,58 @@ bool all_finite(const double* p, int64_t count, bool allow_inf) {
     }
     return true;
 }
+// issymmetric(mP) with tolerance 0, as SolveQuadraticProgram.m:166-168 (the MATLAB implementation raises; the CSR path reads the
+// caller's CSC of P as its CSR and the dense check reads rows of P, so an asymmetric P would silently solve a different problem).
+// Tiled so that both the (i, j) and the (j, i) walk stay inside a cached 64 x 64 block.  Returns -1 or the first offending column.
+int64_t dense_asymmetry(const double* P, int64_t n, int64_t ldp) {
+    for (int64_t j0 = 0; j0 < n; j0 += 64)
+        for (int64_t i0 = j0; i0 < n; i0 += 64) {
+            const int64_t j1 = std::min(n, j0 + 64), i1 = std::min(n, i0 + 64);
+            for (int64_t j = j0; j < j1; ++j)
+                for (int64_t i = std::max(i0, j + 1); i < i1; ++i)
+                    if (P[i + j * ldp] != P[j + i * ldp]) return j;
+        }
+    return -1;
+}
+// Same test on a CSC matrix: columns sorted by row with duplicates summed (what Julia's sparse() guarantees; C callers may not),
+// then compared entry by entry with the transpose built by a counting sort.
+int64_t csc_asymmetry(int64_t n, const int64_t* cp, const int64_t* ri, const double* nz, int base) {
+    const int64_t nnz = cp[n] - base;
+    std::vector<int64_t> scp(n + 1, 0), sri; std::vector<double> snz;
+    sri.reserve((size_t)nnz); snz.reserve((size_t)nnz);
+    std::vector<std::pair<int64_t, double>> col;
+    for (int64_t j = 0; j < n; ++j) {
+        col.clear();
+        for (int64_t k = cp[j] - base; k < cp[j + 1] - base; ++k) col.emplace_back(ri[k] - base, nz[k]);
+        if (!std::is_sorted(col.begin(), col.end(), [](const auto& a, const auto& b) { return a.first < b.first; }))
+            std::stable_sort(col.begin(), col.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (size_t k = 0; k < col.size(); ++k) {
+            if (!sri.empty() && (int64_t)sri.size() > scp[j] && sri.back() == col[k].first) snz.back() += col[k].second;
+            else { sri.push_back(col[k].first); snz.push_back(col[k].second); }
+        }
+        scp[j + 1] = (int64_t)sri.size();
+    }
+    const int64_t snnz = (int64_t)sri.size();
+    std::vector<int64_t> tcp(n + 1, 0), tri((size_t)snnz); std::vector<double> tnz((size_t)snnz);
+    for (int64_t k = 0; k < snnz; ++k) tcp[sri[k] + 1]++;
+    for (int64_t i = 0; i < n; ++i) tcp[i + 1] += tcp[i];
+    {
+        std::vector<int64_t> pos(tcp.begin(), tcp.end() - 1);
+        for (int64_t j = 0; j < n; ++j)
+            for (int64_t k = scp[j]; k < scp[j + 1]; ++k) { const int64_t r = sri[k]; tri[pos[r]] = j; tnz[pos[r]] = snz[k]; pos[r]++; }
+    }
+    // explicit zeros on one side only are still symmetric values: compare through a merge that treats a missing entry as 0
+    for (int64_t j = 0; j < n; ++j) {
+        int64_t a = scp[j], b = tcp[j];
+        while (a < scp[j + 1] || b < tcp[j + 1]) {
+            const int64_t ra = a < scp[j + 1] ? sri[a] : n, rb = b < tcp[j + 1] ? tri[b] : n;
+            if (ra == rb) { if (snz[a] != tnz[b]) return j; ++a; ++b; }
+            else if (ra < rb) { if (snz[a] != 0.0) return j; ++a; }
+            else { if (tnz[b] != 0.0) return j; ++b; }
+        }
+    }
+    return -1;
+}
 int check_device(int device) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return QPS_ERR_NO_DEVICE;
@@ -834,13 +890,18 @@ QPS_API int32_t qps_create_dense(int64_t n, int64_t m, const double* P, int64_t 
     if (!P || !q || (m > 0 && (!A || !l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
     if (ldp < n || (m > 0 && lda < m)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "leading dimension smaller than the row count");
     if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
-    int dc = check_device(device);
-    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
-    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
     for (int64_t j = 0; j < n; ++j) if (!all_finite(P + j * ldp, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P contains NaN/Inf");
     for (int64_t j = 0; j < n && m > 0; ++j) if (!all_finite(A + j * lda, m, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "A contains NaN/Inf");
     if (!all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "q contains NaN/Inf");
     if (m > 0 && (!all_finite(l, m, true) || !all_finite(u, m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
+    {
+        const int64_t bad = dense_asymmetry(P, n, ldp);                              // SolveQuadraticProgram.m:166-168
+        if (bad >= 0) { char b[160]; snprintf(b, sizeof b, "The matrix mP must be a symmetric positive definite matrix (asymmetric entry in column %lld)", (long long)bad); return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, b); }
+    }
+    // argument validation first (a CPU-only caller sees the same errors), the device last
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
     Handle* h = new Handle(); h->n = n; h->m = m;
     int rc = guarded(nullptr, [&] { h->impl = make_dense(device, n, m, dtype, P, ldp, A, lda, q, l, u); });
     if (rc != QPS_OK) { delete h; return rc; }
@@ -858,9 +919,6 @@ QPS_API int32_t qps_create_csc(int64_t n, int64_t m, const int64_t* Pcp, const i
     if (!Pcp || !q || !Acp || (m > 0 && (!l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
     if (index_base != 0 && index_base != 1) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "index_base must be 0 or 1");
     if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
-    int dc = check_device(device);
-    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
-    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
     const int64_t pnnz = Pcp[n] - index_base, annz = Acp[n] - index_base;
     if (Pcp[0] != index_base || Acp[0] != index_base || pnnz < 0 || annz < 0) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr does not start at index_base");
     for (int64_t j = 0; j < n; ++j) if (Pcp[j + 1] < Pcp[j] || Acp[j + 1] < Acp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr not monotone");
@@ -868,6 +926,16 @@ QPS_API int32_t qps_create_csc(int64_t n, int64_t m, const int64_t* Pcp, const i
     for (int64_t k = 0; k < annz; ++k) if (Ari[k] - index_base < 0 || Ari[k] - index_base >= m) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "A row index out of range");
     if (!all_finite(Pnz, pnnz, false) || !all_finite(Anz, annz, false) || !all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P/A/q contain NaN/Inf");
     if (m > 0 && (!all_finite(l, m, true) || !all_finite(u, m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
+    {
+        int64_t bad = -1;
+        int src = guarded(nullptr, [&] { bad = csc_asymmetry(n, Pcp, Pri, Pnz, index_base); });   // SolveQuadraticProgram.m:166-168
+        if (src != QPS_OK) return src;
+        if (bad >= 0) { char b[160]; snprintf(b, sizeof b, "The matrix mP must be a symmetric positive definite matrix (asymmetric entry in column %lld)", (long long)bad); return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, b); }
+    }
+    // argument validation first (a CPU-only caller sees the same errors), the device last
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
     Handle* h = new Handle(); h->n = n; h->m = m;
     int rc;
     if (dense_path) {
@@ -938,12 +1006,15 @@ QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, cons
     if (n <= 0 || m < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1 and m >= 0");
     if (!P || !q || (m > 0 && (!A || !l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
     if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
-    int dc = check_device(device);
-    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
-    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
     if (!all_finite(P, count * n * n, false) || !all_finite(q, count * n, false) || (m > 0 && !all_finite(A, count * m * n, false)))
         return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P/A/q contain NaN/Inf");
     if (m > 0 && (!all_finite(l, count * m, true) || !all_finite(u, count * m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
+    for (int64_t b = 0; b < count; ++b)
+        if (dense_asymmetry(P + b * n * n, n, n) >= 0) { char bf[160]; snprintf(bf, sizeof bf, "QP %lld of the batch: the matrix mP must be a symmetric positive definite matrix", (long long)b); return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, bf); }
+    // argument validation first (a CPU-only caller sees the same errors), the device last
+    int dc = check_device(device);
+    if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+    if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
     Handle* h = new Handle(); h->n = n; h->m = m;
     int rpw = 0;
     const int NPb = roundup(n, 64), MPb = roundup(m, 64);

@@ -31,13 +31,15 @@ def shard_range(total: int, rank: int, world_size: int):
 
 
 def init_process_group(info: RankInfo, prefer: str | None = None):
-    """Returns the backend actually in use ("gloo", or "nccl" == RCCL on ROCm), or None for a single process.
+    """Returns the backend actually in use ("nccl" == RCCL on ROCm, or "gloo"), or None for a single process.
 
-    Default is gloo: the ADMM path has no exchange step, the only traffic is a barrier and two scalars per timed
-    region, and keeping torch off the GPU leaves a single HIP context per rank (the solver's).  QPS_DIST_BACKEND=nccl
-    (or prefer="nccl") routes those scalars through RCCL instead."""
+    The ADMM path has no exchange step: the only traffic is the barrier around a timed region and a MAX / SUM of a few scalars.
+    `prefer` (bench.py: "nccl" when every rank owns a GPU, "gloo" when ranks share a card or there is none; QPS_DIST_BACKEND
+    overrides) is honoured when possible; RCCL needs one distinct device per rank.  A single process creates no group unless
+    QPS_DIST_FORCE_GROUP=1 (used to exercise the RCCL initialisation and all-reduce on a 1-GPU box)."""
     prefer = prefer or os.environ.get("QPS_DIST_BACKEND", "gloo")
-    if info.world_size <= 1:
+    force = os.environ.get("QPS_DIST_FORCE_GROUP") == "1"
+    if info.world_size <= 1 and not force:
         return None
     import torch
     import torch.distributed as dist
@@ -46,21 +48,39 @@ def init_process_group(info: RankInfo, prefer: str | None = None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if dist.is_initialized():
         return dist.get_backend()
-    backend = prefer if (prefer == "gloo" or torch.cuda.is_available()) else "gloo"
+    ndev = torch.cuda.device_count()
+    backend = prefer if (prefer == "gloo" or (ndev >= info.world_size and ndev > 0)) else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(info.local_rank)
-    dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world_size)
+        torch.cuda.set_device(info.local_rank % ndev)
+        dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world_size, device_id=torch.device("cuda", info.local_rank % ndev))
+    else:
+        dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world_size)
     return backend
 
 
+def _grouped():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
+
+
+def shutdown(info: RankInfo):
+    if _grouped():
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def barrier(info: RankInfo):
-    if info.world_size > 1:
+    if _grouped():
         import torch.distributed as dist
         dist.barrier()
 
 
 def _reduce(info: RankInfo, values, op_name: str):
-    if info.world_size <= 1:
+    if not _grouped():
         return [float(v) for v in values]
     import torch
     import torch.distributed as dist

@@ -76,6 +76,36 @@ def test_c_abi_status_codes_without_touching_the_gpu(qps):
     assert L.qps_destroy(None) == 0
 
 
+def test_asymmetric_p_is_refused_like_issymmetric(qps):
+    """SolveQuadraticProgram.m:166-168: `if(~issymmetric(mP)) error(...)`, tolerance 0.  Checked before the device is
+    touched, for the dense, the CSC and the batch constructors."""
+    import scipy.sparse as sp
+    from quadraticprogramsolver_amd import _lib
+    n, m = 70, 5
+    rng = np.random.default_rng(0)
+    M = rng.standard_normal((n, n)); P = M.T @ M + np.eye(n); P = 0.5 * (P + P.T)
+    q, A, l, u = np.zeros(n), rng.standard_normal((m, n)), -np.ones(m), np.ones(m)
+    Pbad = P.copy(); Pbad[66, 3] = np.nextafter(Pbad[66, 3], np.inf)       # one ulp off, far from the diagonal
+    for bad in (Pbad, sp.csc_matrix(Pbad)):
+        with pytest.raises(qps.QpsError) as e:
+            qps.QuadraticProgram(bad, q, A, l, u)
+        assert e.value.status == 1 and "symmetric" in str(e.value)
+    with pytest.raises(qps.QpsError) as e:
+        qps.QuadraticProgramBatch([(P, q, A, l, u), (Pbad, q, A, l, u)])
+    assert e.value.status == 1 and "QP 1" in str(e.value)
+    # structurally asymmetric sparse pattern (an entry without its mirror image)
+    S = sp.lil_matrix(sp.eye(n)); S[2, 40] = 0.5
+    with pytest.raises(qps.QpsError) as e:
+        qps.QuadraticProgram(S.tocsc(), q, sp.csc_matrix(A), l, u, linsys="cg")
+    assert e.value.status == 1
+    # symmetric inputs pass the check and reach the device test (status 7 without a GPU); unsorted CSC columns are accepted
+    if _lib.lib().qps_device_count() == 0:
+        for good in (P, sp.csc_matrix(P)):
+            with pytest.raises(qps.QpsError) as e:
+                qps.QuadraticProgram(good, q, A, l, u)
+            assert e.value.status == 7
+
+
 def test_fails_loudly_without_a_gpu(qps):
     from quadraticprogramsolver_amd import _lib
     if _lib.lib().qps_device_count() > 0:

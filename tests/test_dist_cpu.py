@@ -50,3 +50,33 @@ def test_two_rank_gloo_timing_reduction():
         assert tmax == 2.0                   # MAX over ranks
         assert s == 10.0                     # the two slabs cover the batch
         assert value == pytest.approx(1000.0 / 2.0)   # whole-job units / slowest rank
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) must itself start two ranks: the selftest mode runs the rank plumbing
+    (rendezvous on 127.0.0.1, barrier, MAX / SUM reduction, one JSON line from rank 0) without a solver call, so it runs on CPU."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--config", "c1", "--launcher-selftest"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_counted"] == 2 and out["steps_counted"] == 6 and out["selftest"] is True
+    assert out["config"]["dist_backend"] == "gloo"            # no GPU here: ranks share no card -> gloo
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    r = _run_bench(["--gpus", "2", "--launcher-selftest"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    r = _run_bench(["--gpus", "1", "--launcher-selftest"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
