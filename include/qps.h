@@ -55,7 +55,11 @@ typedef enum { QPS_F64 = 0, QPS_F32 = 1 } qps_dtype;
 typedef enum {
     QPS_LINSYS_AUTO = 0,        /* dense handle -> QPS_LINSYS_CHOLESKY, CSC handle -> QPS_LINSYS_CG                */
     QPS_LINSYS_CHOLESKY = 1,    /* reduced form P + sigma I + rho A'A, one Cholesky + two triangular sweeps / it   */
-    QPS_LINSYS_CG = 2           /* matrix-free CG on the reduced operator (LinearSystemSolvers.jl:145-186)         */
+    QPS_LINSYS_CG = 2,          /* matrix-free CG on the reduced operator (LinearSystemSolvers.jl:145-186)         */
+    QPS_LINSYS_KKT_LDL = 3      /* sparse L D L' of the quasi-definite KKT matrix [P + sigma I  A'; A  -I/rho], the reference's
+                                   direct plugins LaLdl / QDLdl / FacLdl (LinearSystemSolvers.jl:16-107): minimum-degree ordering
+                                   and symbolic factor once per handle, numeric-only re-factorisation on a rho switch, two
+                                   level-scheduled sparse triangular solves per iteration.  CSC handles created with dense_path = 0 */
 } qps_linsys_kind;
 
 /* Keyword arguments of SolveQuadraticProgram! (SolveQuadraticProgram.jl:15-17), same names, same defaults.
@@ -211,6 +215,29 @@ int32_t qps_proxqp_init_kkt(qps_handle h);
 int32_t qps_proxqp_set_state(qps_handle h, const double *x, const double *y, const double *z, const double *s);
 int32_t qps_proxqp_get_state(qps_handle h, double *x, double *y, double *z, double *s);
 int32_t qps_proxqp_solve(qps_handle h, const qps_proxqp_params *params, qps_proxqp_report *report);
+
+/* The modeAuto rule of SolveQuadraticProgramRef! (SolveQuadraticProgram.jl:129-130, :143-151; SolveQuadraticProgram.m:190-199):
+ * numRowsL = n + m, nnzDensity = (nnz(P) + nnz(A)) / numRowsL^2; direct when numRowsL <= 5000 and nnzDensity <= 0.4, else
+ * iterative.  Returns the qps_linsys_kind to use: QPS_LINSYS_CG (iterative), or for "direct" QPS_LINSYS_KKT_LDL when the caller
+ * holds sparse matrices (sparse_input != 0; the reference's ldlt / decomposition(...,'ldl') of the sparse KKT matrix) and
+ * QPS_LINSYS_CHOLESKY for dense arrays.  Pure function: no handle, no device. */
+int32_t qps_linsys_auto(int64_t n, int64_t m, int64_t nnzP, int64_t nnzA, int32_t sparse_input);
+
+/* Symbolic analysis of the KKT matrix for QPS_LINSYS_KKT_LDL on its own (host only, no device needed): what LaLdlInit / QDLdlInit /
+ * FacLdlInit do before the numeric factorisation (LinearSystemSolvers.jl:18, :49, :81).  perm_out (n + m entries, may be NULL)
+ * receives the elimination order over [x; nu] in the caller's index base; the report sizes the factor. */
+typedef struct {
+    int64_t numRows;            /* n + m */
+    int64_t numSparseColumns;   /* columns kept as scalar sparse columns (wide elimination-tree levels) */
+    int64_t tailSize;           /* columns near the root handled as one dense block */
+    int64_t numSparseLevels;    /* launches per triangular sweep over the sparse part */
+    int64_t treeHeight;         /* height of the elimination tree */
+    int64_t nnzK;               /* strictly lower triangle of K */
+    int64_t nnzL;               /* strictly lower triangle of L under the minimum-degree ordering */
+    int64_t nnzStored;          /* entries actually stored (the tail counted as dense) */
+} qps_ldl_report;
+int32_t qps_ldl_analyze(int64_t n, int64_t m, const int64_t *P_colptr, const int64_t *P_rowval, const int64_t *A_colptr,
+                        const int64_t *A_rowval, int32_t index_base, int64_t *perm_out, qps_ldl_report *report);
 
 int32_t qps_destroy(qps_handle h);
 /* Human-readable description of the last failure on this handle (or of the last failed create when h == NULL). */

@@ -11,7 +11,7 @@ import scipy.sparse as sp
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libqps_oracle.so")
 
-KIND_RED_CHOL, KIND_KKT_LDL, KIND_CG_EXPLICIT, KIND_CG_MATFREE = 0, 1, 2, 3
+KIND_RED_CHOL, KIND_KKT_LDL, KIND_CG_EXPLICIT, KIND_CG_MATFREE, KIND_KKT_LDL_SPARSE = 0, 1, 2, 3, 4
 
 
 class OqParams(C.Structure):
@@ -88,10 +88,30 @@ def make_params(numIterations=5000, epsAbs=1e-6, epsRel=1e-6, rho=1.0, sigma=1e-
                     float(fctrRho), epsPcg, numItrPcg, numThreads, loopThreads, 0)
 
 
-def solve(mP, vQ, mA, vL, vU, vX=None, **kw):
-    """Run the C restatement.  Dense (ndarray) or sparse (scipy) inputs.  Returns (x, info dict incl. z, y)."""
+def kkt_ordering(mP, mA):
+    """A fill-reducing ordering of the KKT pattern for linsys kind 4, from a third-party code that shares nothing with the
+    product: SuperLU's multiple-minimum-degree ordering of A' + A (scipy.sparse.linalg.splu, symmetric mode).  perm[new] = old."""
+    import scipy.sparse.linalg as spla
+    n, m = mP.shape[0], mA.shape[0]
+    Pp = sp.csc_matrix(mP).astype(bool).astype(np.float64)
+    Ap = sp.csc_matrix(mA).astype(bool).astype(np.float64)
+    K = sp.bmat([[Pp + sp.eye(n), Ap.T], [Ap, sp.eye(m)]], format="csc") + (n + m) * sp.eye(n + m, format="csc")   # pattern only, diagonally dominant
+    lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    return np.ascontiguousarray(np.argsort(lu.perm_c), dtype=np.int64)      # (perm_c itself is the inverse map: 240x the fill)
+
+
+def solve(mP, vQ, mA, vL, vU, vX=None, perm=None, **kw):
+    """Run the C restatement.  Dense (ndarray) or sparse (scipy) inputs.  Returns (x, info dict incl. z, y).
+    linsys=KIND_KKT_LDL_SPARSE: ``perm`` (perm[new] = old over [x; nu]) orders the sparse L D L'; default ``kkt_ordering``."""
     n = mP.shape[0]
     m = mA.shape[0]
+    keep = None
+    if kw.get("linsys") == KIND_KKT_LDL_SPARSE:
+        keep = np.ascontiguousarray(kkt_ordering(mP, mA) if perm is None else perm, dtype=np.int64)
+        assert sorted(keep.tolist()) == list(range(n + m))
+        lib().oq_set_kkt_perm(_ip(keep))
+    else:
+        lib().oq_set_kkt_perm(None)
     if not kw.get("numThreads"):
         kw["numThreads"] = min(available_cores(), 16)
     prm = make_params(**kw)

@@ -15,7 +15,9 @@
  * What is restated
  *   loop            SolveQuadraticProgram.jl:14-76   -> oq_solve_*()
  *   convergence     SolveQuadraticProgram.jl:79-112  -> check_convergence()
- *   KKT plugins     LinearSystemSolvers.jl:16-107    -> linsys kind 1 (dense LDLt of the quasi-definite KKT matrix)
+ *   KKT plugins     LinearSystemSolvers.jl:16-107    -> linsys kind 1 (dense LDLt of the quasi-definite KKT matrix) and kind 4
+ *                                                       (sparse CSC LDLt in the manner of QDLDL: elimination tree, column counts,
+ *                                                       up-looking numeric factorisation, :47-75; the ordering is an input)
  *   reduced plugins LinearSystemSolvers.jl:110-142   -> linsys kind 0 (Cholesky instead of cg!, cf. ProxQP.jl:175-206,221-225)
  *                                                       and kind 2 (cg! on the explicit reduced matrix)
  *   matrix-free     LinearSystemSolvers.jl:145-186   -> linsys kind 3 (operator P w + rho A'(A w) + sigma w)
@@ -277,6 +279,128 @@ static void dense_ldlt_solve(int64_t N, const double *K, double *b) {
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Sparse L D L' of a symmetric quasi-definite matrix given by its upper triangle in CSC (0-based), the algorithm QDLDL
+ * publishes (Stellato et al., "OSQP", Math. Prog. Comp. 2020, sec. 4; QDLDL.jl is what QDLdlInit calls,
+ * LinearSystemSolvers.jl:49): (1) elimination tree and column counts from the upper triangle, (2) up-looking numeric
+ * factorisation -- row k of L solves a sparse triangular system whose pattern is the reach of column k in the tree,
+ * (3) L x = b, x ./= D, L' x = x.  No pivoting: a quasi-definite matrix has an L D L' for every symmetric permutation.
+ * QDLDL.jl is un-vendored and unpinned; its ordering (AMD) is replaced by a caller-supplied permutation, which changes
+ * round-off only.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t N;
+    int64_t *Ap, *Ai; double *Ax;      /* upper triangle (incl. diagonal) of the PERMUTED matrix, CSC, sorted rows */
+    int64_t *etree, *Lnz, *Lp, *Li; double *Lx, *D, *Dinv;
+    int64_t *perm, *iperm;             /* perm[new] = old */
+    double *work;                      /* N doubles: permuted right-hand side */
+} sp_ldl;
+
+static void sp_ldl_free(sp_ldl *f) {
+    if (!f) return;
+    free(f->Ap); free(f->Ai); free(f->Ax); free(f->etree); free(f->Lnz); free(f->Lp); free(f->Li); free(f->Lx); free(f->D); free(f->Dinv);
+    free(f->perm); free(f->iperm); free(f->work); free(f);
+}
+/* elimination tree and the number of off-diagonal entries of every column of L */
+static int64_t sp_ldl_etree(sp_ldl *f) {
+    int64_t N = f->N, total = 0;
+    int64_t *mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) { f->etree[j] = -1; f->Lnz[j] = 0; mark[j] = -1; }
+    for (int64_t j = 0; j < N; ++j) {
+        mark[j] = j;
+        for (int64_t p = f->Ap[j]; p < f->Ap[j + 1]; ++p) {
+            int64_t i = f->Ai[p];
+            while (i < j && mark[i] != j) {           /* walk from i towards the root until a node already seen for column j */
+                if (f->etree[i] == -1) f->etree[i] = j;
+                f->Lnz[i]++; total++;                  /* L_ji is a non-zero of column i */
+                mark[i] = j;
+                i = f->etree[i];
+            }
+        }
+    }
+    free(mark);
+    return total;
+}
+/* numeric factorisation; returns 0 or 1 + the index of a zero pivot */
+static int64_t sp_ldl_numeric(sp_ldl *f) {
+    int64_t N = f->N;
+    int64_t *next = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);      /* next free slot of every column of L */
+    int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (size_t)N), *path = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int64_t *mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    double *y = (double *)calloc((size_t)N, sizeof(double));
+    int64_t fail = 0;
+    for (int64_t j = 0; j < N; ++j) { next[j] = f->Lp[j]; mark[j] = -1; }
+    for (int64_t k = 0; k < N && !fail; ++k) {
+        /* pattern of row k of L = reach of the non-zeros of column k (upper triangle) in the tree, in topological order */
+        int64_t top = N; double d = 0.0;
+        mark[k] = k;
+        for (int64_t p = f->Ap[k]; p < f->Ap[k + 1]; ++p) {
+            int64_t i = f->Ai[p];
+            if (i == k) { d = f->Ax[p]; continue; }
+            y[i] = f->Ax[p];
+            int64_t len = 0;
+            for (; mark[i] != k; i = f->etree[i]) { path[len++] = i; mark[i] = k; }
+            while (len > 0) stack[--top] = path[--len];
+        }
+        for (int64_t t = top; t < N; ++t) {
+            int64_t j = stack[t];
+            double yj = y[j]; y[j] = 0.0;
+            for (int64_t p = f->Lp[j]; p < next[j]; ++p) y[f->Li[p]] -= f->Lx[p] * yj;   /* rows of column j computed so far */
+            double lkj = yj * f->Dinv[j];
+            d -= yj * lkj;
+            f->Li[next[j]] = k; f->Lx[next[j]] = lkj; next[j]++;
+        }
+        if (d == 0.0 || isnan(d)) { fail = k + 1; break; }
+        f->D[k] = d; f->Dinv[k] = 1.0 / d;
+    }
+    free(next); free(stack); free(path); free(mark); free(y);
+    return fail;
+}
+static void sp_ldl_solve(const sp_ldl *f, double *b) {     /* b in the ORIGINAL numbering, solved in place */
+    int64_t N = f->N; double *x = f->work;
+    for (int64_t k = 0; k < N; ++k) x[k] = b[f->perm[k]];
+    for (int64_t j = 0; j < N; ++j) { double xj = x[j]; for (int64_t p = f->Lp[j]; p < f->Lp[j + 1]; ++p) x[f->Li[p]] -= f->Lx[p] * xj; }
+    for (int64_t j = 0; j < N; ++j) x[j] *= f->Dinv[j];
+    for (int64_t j = N - 1; j >= 0; --j) { double s = x[j]; for (int64_t p = f->Lp[j]; p < f->Lp[j + 1]; ++p) s -= f->Lx[p] * x[f->Li[p]]; x[j] = s; }
+    for (int64_t k = 0; k < N; ++k) b[f->perm[k]] = x[k];
+}
+/* symbolic part for a matrix given as (row, col, value) triplets of its upper triangle in the original numbering */
+static sp_ldl *sp_ldl_symbolic(int64_t N, int64_t nt, const int64_t *tr, const int64_t *tc, const int64_t *perm) {
+    sp_ldl *f = (sp_ldl *)calloc(1, sizeof(sp_ldl));
+    f->N = N;
+    f->perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)N); f->iperm = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    for (int64_t k = 0; k < N; ++k) { f->perm[k] = perm ? perm[k] : k; f->iperm[f->perm[k]] = k; }
+    f->Ap = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t)); f->Ai = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nt > 0 ? nt : 1));
+    f->Ax = (double *)calloc((size_t)(nt > 0 ? nt : 1), sizeof(double));
+    for (int64_t e = 0; e < nt; ++e) { int64_t a = f->iperm[tr[e]], b = f->iperm[tc[e]]; f->Ap[(a > b ? a : b) + 1]++; }
+    for (int64_t j = 0; j < N; ++j) f->Ap[j + 1] += f->Ap[j];
+    f->etree = (int64_t *)malloc(sizeof(int64_t) * (size_t)N); f->Lnz = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    f->Lp = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t));
+    f->D = (double *)malloc(sizeof(double) * (size_t)N); f->Dinv = (double *)malloc(sizeof(double) * (size_t)N);
+    f->work = (double *)malloc(sizeof(double) * (size_t)N);
+    return f;
+}
+/* (re)load the values: triplet e goes to slot pos[e] of the permuted CSC (pos is built on the first call) */
+static void sp_ldl_load(sp_ldl *f, int64_t nt, const int64_t *tr, const int64_t *tc, const double *tv, int64_t **pos_io) {
+    int64_t N = f->N;
+    if (!*pos_io) {
+        int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nt > 0 ? nt : 1));
+        int64_t *next = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+        for (int64_t j = 0; j < N; ++j) next[j] = f->Ap[j];
+        for (int64_t e = 0; e < nt; ++e) {
+            int64_t a = f->iperm[tr[e]], b = f->iperm[tc[e]]; int64_t col = a > b ? a : b, row = a > b ? b : a;
+            pos[e] = next[col]++; f->Ai[pos[e]] = row;
+        }
+        free(next);
+        *pos_io = pos;
+        int64_t total = sp_ldl_etree(f);
+        for (int64_t j = 0; j < N; ++j) f->Lp[j + 1] = f->Lp[j] + f->Lnz[j];
+        f->Li = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total > 0 ? total : 1));
+        f->Lx = (double *)malloc(sizeof(double) * (size_t)(total > 0 ? total : 1));
+    }
+    for (int64_t e = 0; e < nt; ++e) f->Ax[(*pos_io)[e]] = tv[e];
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Linear-system plugins.  Interface mirrors the reference plugin pair
  *   Init(vX, mP, vQ, mA, rho, rho1, sigma, n, m) -> (vXX, vZZ, tuSolver)        LinearSystemSolvers.jl:16,24
  *   Sol!(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, rho, rho1, sigma, n, m, changedRho)   :28,42
@@ -293,7 +417,10 @@ typedef struct {
     double epsPcg; int32_t numItrPcg;
     int32_t cgIterations;
     int64_t fail;
+    sp_ldl *sp; int64_t sp_nt; int64_t *sp_tr, *sp_tc, *sp_pos; double *sp_tv; int64_t sp_rho_first;   /* kind 4: triplets of triu(K); the last m are the -1/rho diagonal */
 } oq_linsys;
+
+static const int64_t *g_kkt_perm = NULL;   /* ordering for kind 4 (perm[new] = old over [x; nu]); NULL = natural order */
 
 static void dense_P_dense(const oq_prob *p, double *out) { /* materialise P as dense column-major */
     int64_t n = p->n;
@@ -329,6 +456,11 @@ static void linsys_factor(oq_linsys *s, double rho, double rho1, double sigma) {
         for (int64_t i = 0; i < m; ++i) K[(n + i) + (n + i) * N] = -rho1;
         free(Pd); free(Ad);
         s->fail = dense_ldlt(N, K);
+    } else if (s->kind == 4) {
+        /* LinearSystemSolvers.jl:49 / :62  QDLDL.qdldl([mP + sigma I  mA'; mA  -rho1 I]): only the last m triplets change with rho */
+        for (int64_t i = 0; i < m; ++i) s->sp_tv[s->sp_rho_first + i] = -rho1;
+        sp_ldl_load(s->sp, s->sp_nt, s->sp_tr, s->sp_tc, s->sp_tv, &s->sp_pos);
+        s->fail = sp_ldl_numeric(s->sp);
     }
     (void)sigma;
 }
@@ -337,7 +469,9 @@ static oq_linsys *linsys_init(int kind, const oq_prob *p, double rho, double rho
     oq_linsys *s = (oq_linsys *)calloc(1, sizeof(oq_linsys));
     int64_t n = p->n, m = p->m;
     s->kind = kind; s->p = p; s->epsPcg = epsPcg; s->numItrPcg = numItrPcg;
-    if (kind == 1) {
+    if (kind == 4) {
+        /* buffers are allocated with the triplets below */
+    } else if (kind == 1) {
         s->vV = (double *)calloc((size_t)(n + m), sizeof(double));              /* :19 zeros(m + n) */
         s->vXX = s->vV; s->vZZ = s->vV + n;                                       /* :21-22 views */
         s->F = (double *)malloc(sizeof(double) * (size_t)((n + m) * (n + m)));
@@ -357,6 +491,36 @@ static oq_linsys *linsys_init(int kind, const oq_prob *p, double rho, double rho
             else { double *Ad = (double *)malloc(sizeof(double) * (size_t)(n * m)); dense_A_dense(p, Ad); dense_AtA(m, n, Ad, s->mAA); free(Ad); }
         } else memset(s->mAA, 0, sizeof(double) * (size_t)(n * n));
     }
+    if (kind == 4) {
+        /* triplets of the upper triangle of K in the [x; nu] numbering: triu(P) + sigma I, A' (rows < n, columns >= n), -rho1 I */
+        int64_t cap = n + m + 1; 
+        if (p->sparse) cap += p->Pcp[n] + p->Acp[n]; else cap += n * n + n * m;
+        s->sp_tr = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap); s->sp_tc = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+        s->sp_tv = (double *)malloc(sizeof(double) * (size_t)cap);
+        int64_t nt = 0;
+        double *dg = (double *)calloc((size_t)n, sizeof(double));
+        if (p->sparse) {
+            for (int64_t j = 0; j < n; ++j) for (int64_t k = p->Pcp[j]; k < p->Pcp[j + 1]; ++k) {
+                int64_t i = p->Pri[k];
+                if (i == j) dg[j] += p->Pnz[k]; else if (i < j) { s->sp_tr[nt] = i; s->sp_tc[nt] = j; s->sp_tv[nt] = p->Pnz[k]; nt++; }
+            }
+            for (int64_t j = 0; j < n; ++j) for (int64_t k = p->Acp[j]; k < p->Acp[j + 1]; ++k) { s->sp_tr[nt] = j; s->sp_tc[nt] = n + p->Ari[k]; s->sp_tv[nt] = p->Anz[k]; nt++; }
+        } else {
+            for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i <= j; ++i) {
+                double v = p->P[i + j * n];
+                if (i == j) dg[j] = v; else if (v != 0.0) { s->sp_tr[nt] = i; s->sp_tc[nt] = j; s->sp_tv[nt] = v; nt++; }
+            }
+            for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < m; ++i) { double v = p->A[i + j * m]; if (v != 0.0) { s->sp_tr[nt] = j; s->sp_tc[nt] = n + i; s->sp_tv[nt] = v; nt++; } }
+        }
+        for (int64_t j = 0; j < n; ++j) { s->sp_tr[nt] = j; s->sp_tc[nt] = j; s->sp_tv[nt] = dg[j] + sigma; nt++; }
+        s->sp_rho_first = nt;
+        for (int64_t i = 0; i < m; ++i) { s->sp_tr[nt] = n + i; s->sp_tc[nt] = n + i; s->sp_tv[nt] = -rho1; nt++; }
+        free(dg);
+        s->sp_nt = nt;
+        s->sp = sp_ldl_symbolic(n + m, nt, s->sp_tr, s->sp_tc, g_kkt_perm);
+        s->vV = (double *)calloc((size_t)(n + m), sizeof(double));               /* :50 zeros(m + n); vXX / vZZ are views (:52-53) */
+        s->vXX = s->vV; s->vZZ = s->vV + n;
+    }
     if (kind == 2 || kind == 3) {
         s->cg_u = (double *)calloc((size_t)n, sizeof(double));
         s->cg_r = (double *)calloc((size_t)n, sizeof(double));
@@ -369,7 +533,8 @@ static oq_linsys *linsys_init(int kind, const oq_prob *p, double rho, double rho
 }
 static void linsys_free(oq_linsys *s) {
     if (!s) return;
-    if (s->kind == 1) free(s->vV); else { free(s->vXX); free(s->vZZ); free(s->vT); }
+    if (s->kind == 1 || s->kind == 4) free(s->vV); else { free(s->vXX); free(s->vZZ); free(s->vT); }
+    sp_ldl_free(s->sp); free(s->sp_tr); free(s->sp_tc); free(s->sp_tv); free(s->sp_pos);
     free(s->F); free(s->mPI); free(s->mAA); free(s->cg_u); free(s->cg_r); free(s->cg_c); free(s->cg_t); free(s->cg_tmp_m);
     free(s);
 }
@@ -424,10 +589,11 @@ static void linsys_solve(oq_linsys *s, const double *vX, const double *vQ, const
                          double rho, double rho1, double sigma, int changedRho) {
     const oq_prob *p = s->p; int64_t n = p->n, m = p->m;
     if (changedRho) linsys_factor(s, rho, rho1, sigma);   /* :30-32, :61-63, :93-95, :127-129 */
-    if (s->kind == 1) {
+    if (s->kind == 1 || s->kind == 4) {
         for (int64_t i = 0; i < n; ++i) s->vXX[i] = sigma * vX[i] - vQ[i];        /* :37 */
         for (int64_t i = 0; i < m; ++i) s->vZZ[i] = vZ[i] - rho1 * vY[i];         /* :38 */
-        dense_ldlt_solve(n + m, s->F, s->vV);                                     /* :39 / :70 / :102 */
+        if (s->kind == 1) dense_ldlt_solve(n + m, s->F, s->vV);                   /* :39 / :70 / :102 */
+        else sp_ldl_solve(s->sp, s->vV);                                          /* :70 QDLDL.solve!(hDL, vV) */
         for (int64_t i = 0; i < m; ++i) s->vZZ[i] = vZ[i] + rho1 * (s->vZZ[i] - vY[i]); /* :40 */
     } else {
         for (int64_t i = 0; i < m; ++i) s->vZZ[i] = rho * vZ[i] - vY[i];          /* :134 vZZ used as buffer */
@@ -558,6 +724,9 @@ OQ_EXPORT int32_t oq_linsys_solve_dense(void *hh, const double *x, const double 
     return (int32_t)h->s->fail;
 }
 OQ_EXPORT void oq_linsys_free(void *hh) { oq_plugin *h = (oq_plugin *)hh; if (!h) return; linsys_free(h->s); free(h->q); free(h); }
+
+/* ordering used by linsys kind 4 (perm[new] = old over [x; nu], n + m entries; NULL = natural order); the array must stay alive */
+OQ_EXPORT void oq_set_kkt_perm(const int64_t *perm) { g_kkt_perm = perm; }
 
 OQ_EXPORT int32_t oq_max_threads(void) {
 #ifdef _OPENMP

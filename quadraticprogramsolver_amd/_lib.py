@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
     "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
     "qps_proxqp_default_params", "qps_proxqp_create_dense", "qps_proxqp_init_kkt", "qps_proxqp_set_state", "qps_proxqp_get_state",
-    "qps_proxqp_solve", "qps_polish",
+    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze",
 ]
 
 QPS_OK = 0
@@ -28,7 +28,7 @@ STATUS_NAMES = {0: "QPS_OK", 1: "QPS_ERR_BAD_ARGUMENT", 2: "QPS_ERR_BAD_DIMENSIO
                 4: "QPS_ERR_FACTORIZATION", 5: "QPS_ERR_HIP", 6: "QPS_ERR_OUT_OF_MEMORY", 7: "QPS_ERR_NO_DEVICE",
                 8: "QPS_ERR_UNSUPPORTED"}
 QPS_F64, QPS_F32 = 0, 1
-QPS_LINSYS_AUTO, QPS_LINSYS_CHOLESKY, QPS_LINSYS_CG = 0, 1, 2
+QPS_LINSYS_AUTO, QPS_LINSYS_CHOLESKY, QPS_LINSYS_CG, QPS_LINSYS_KKT_LDL = 0, 1, 2, 3
 
 
 class QpsLibraryError(RuntimeError):
@@ -80,6 +80,13 @@ class QpsProxQpParams(C.Structure):
 class QpsProxQpReport(C.Structure):
     _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("rho", C.c_double), ("sigma", C.c_double),
                 ("resPrim", C.c_double), ("resDual", C.c_double)]
+
+
+class QpsLdlReport(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("numRows", "numSparseColumns", "tailSize", "numSparseLevels", "treeHeight", "nnzK", "nnzL", "nnzStored")]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
 
 
 class QpsKernelTime(C.Structure):
@@ -135,6 +142,8 @@ def lib() -> C.CDLL:
     L.qps_proxqp_set_state.argtypes = [hp, dp, dp, dp, dp]
     L.qps_proxqp_get_state.argtypes = [hp, dp, dp, dp, dp]
     L.qps_proxqp_solve.argtypes = [hp, C.POINTER(QpsProxQpParams), C.POINTER(QpsProxQpReport)]
+    L.qps_linsys_auto.argtypes = [i64, i64, i64, i64, i32]
+    L.qps_ldl_analyze.argtypes = [i64, i64, ip, ip, ip, ip, i32, ip, C.POINTER(QpsLdlReport)]
     L.qps_destroy.argtypes = [hp]
     L.qps_last_error.argtypes = [hp]
     L.qps_last_error.restype = C.c_char_p

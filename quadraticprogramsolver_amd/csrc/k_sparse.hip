@@ -16,6 +16,7 @@
 
 #include "qps_internal.h"
 #include "qps_kernels.h"
+#include "qps_ldl.h"
 #include "qps_polish.h"
 #include "wave_reduce.h"
 
@@ -360,7 +361,11 @@ template <typename T> struct SparseSolver : SolverBase {
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     int nb_n = 0, nb_op = 0; int64_t cg_total = 0; int last_cg = 4;
     double eps_pcg = 1e-6; int itr_pcg = 1000;
-    int cat_spmv, cat_op, cat_vec, cat_chk;
+    int cat_spmv, cat_op, cat_vec, cat_chk, cat_ldl;
+    // sparse direct KKT plugin (LinearSystemSolvers.jl:16-107): built on first use from canonical host copies of the caller's CSC
+    std::vector<int64_t> hPcp, hPri, hAcp, hAri; std::vector<double> hPnz, hAnz;
+    std::unique_ptr<SparseLdl<T>> ldl; bool ldl_valid = false; double ldl_rho = 0, ldl_sigma = 0; int plugin_kind = QPS_LINSYS_CG;
+    int num_factorizations = 0;
 
     // column-blocked copy for k_spmv_blk: per block a CSR with 16-bit local column indices + its task list
     void build_blocked(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
@@ -455,6 +460,43 @@ template <typename T> struct SparseSolver : SolverBase {
         HIPC(hipMemcpyAsync(h, stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
     }
+    static void canonical_csc(int ncols, const int64_t* cp, const int64_t* ri, const double* nz, int base, std::vector<int64_t>& ocp,
+                              std::vector<int64_t>& ori, std::vector<double>& onz) {
+        ocp.assign(ncols + 1, 0); ori.clear(); onz.clear();
+        ori.reserve((size_t)(cp[ncols] - base)); onz.reserve((size_t)(cp[ncols] - base));
+        std::vector<std::pair<int64_t, double>> col;
+        for (int j = 0; j < ncols; ++j) {
+            col.clear();
+            for (int64_t k = cp[j] - base; k < cp[j + 1] - base; ++k) col.emplace_back(ri[k] - base, nz[k]);
+            auto less = [](const std::pair<int64_t, double>& a, const std::pair<int64_t, double>& b) { return a.first < b.first; };
+            if (!std::is_sorted(col.begin(), col.end(), less)) std::stable_sort(col.begin(), col.end(), less);
+            for (size_t k = 0; k < col.size(); ++k) {
+                if ((int64_t)ori.size() > ocp[j] && ori.back() == col[k].first) onz.back() += col[k].second;
+                else { ori.push_back(col[k].first); onz.push_back(col[k].second); }
+            }
+            ocp[j + 1] = (int64_t)ori.size();
+        }
+    }
+    // LaLdlInit / QDLdlInit / FacLdlInit (LinearSystemSolvers.jl:16-24, :47-55, :78-86): ordering + symbolic once per handle, numeric per (rho, sigma)
+    void ldl_prepare(double rho, double sigma, bool force) {
+        if (!ldl) {
+            if (n + m > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "KKT matrix too large for the sparse direct plugin");
+            static const int max_tail = [] { const char* e = getenv("QPS_LDL_MAX_TAIL"); return e ? atoi(e) : 8192; }();
+            static const int min_level = [] { const char* e = getenv("QPS_LDL_MIN_LEVEL"); return e ? atoi(e) : 64; }();
+            static const int max_levels = [] { const char* e = getenv("QPS_LDL_MAX_LEVELS"); return e ? atoi(e) : 4096; }();
+            LdlSymbolic sym;
+            try { sym = ldl_analyze((int)n, (int)m, hPcp.data(), hPri.data(), hAcp.data(), hAri.data(), 0, max_tail, min_level, max_levels); }
+            catch (const std::runtime_error& e) { throw QpsError(QPS_ERR_UNSUPPORTED, e.what()); }
+            ldl = make_sparse_ldl<T>(st, std::move(sym), hPnz.data(), (int64_t)hPnz.size(), hAnz.data(), (int64_t)hAnz.size());
+            ldl_valid = false;
+        }
+        if (force || !ldl_valid || ldl_rho != rho || ldl_sigma != sigma) {
+            ldl_valid = false;
+            ++num_factorizations;
+            ldl->factorize(rho, sigma);
+            ldl_valid = true; ldl_rho = rho; ldl_sigma = sigma;
+        }
+    }
 
     SparseSolver(int dev, int64_t n_, int64_t m_, int dt, const int64_t* Pcp, const int64_t* Pri, const double* Pnz,
                  const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* qh, const double* lh, const double* uh, int base) {
@@ -477,6 +519,8 @@ template <typename T> struct SparseSolver : SolverBase {
             for (int64_t j = 0; j < n; ++j)
                 for (int k = atrp[j]; k < atrp[j + 1]; ++k) { const int r = atci[k]; aci[pos[r]] = (int)j; ava[pos[r]] = atva[k]; pos[r]++; }
         }
+        canonical_csc((int)n, Pcp, Pri, Pnz, base, hPcp, hPri, hPnz);     // sorted rows, duplicates summed, 0-based: input of the LDL' plugin
+        canonical_csc((int)n, Acp, Ari, Anz, base, hAcp, hAri, hAnz);
         upload_csr(P, (int)n, (int)n, prp, pci, pva);
         upload_csr(At, (int)n, (int)m, atrp, atci, atva);
         upload_csr(A, (int)m, (int)n, arp, aci, ava);
@@ -510,6 +554,7 @@ template <typename T> struct SparseSolver : SolverBase {
         cat_op = prof.category("cg_iteration(A u, P u + rho A'. + sigma u, axpys)", spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m) + spmv_bytes(P, (int)n) + s * 10.0 * n);
         cat_vec = prof.category("admm_update", s * (3.0 * n + 7.0 * m));
         cat_chk = prof.category("check_convergence", spmv_bytes(A, (int)n) + spmv_bytes(At, (int)m) + spmv_bytes(P, (int)n));
+        cat_ldl = prof.category("kkt_ldl_solve(rhs, level sweeps, dense tail, post)", 0.0);   // bytes are known once the factor exists
         // The CSR arrays went up with synchronous hipMemcpy from pageable memory: that returns once the data is staged, the DMA
         // may still be running on the null stream, and the solver stream is not ordered against it.
         HIPC(hipDeviceSynchronize());
@@ -614,8 +659,13 @@ template <typename T> struct SparseSolver : SolverBase {
         return state_host->iters;
     }
 
-    // LinOpCg! body (LinearSystemSolvers.jl:176-181)
+    // LinOpCg! body (LinearSystemSolvers.jl:176-181), or the direct KKT plugins' Sol! body (:37-40)
     void linear_solve(double rho, double sigma) {
+        if (plugin_kind == QPS_LINSYS_KKT_LDL) {
+            ProfScope ps(prof, cat_ldl, 2);
+            ldl->solve(x, q, z, y, rho, sigma, xx, zz);
+            return;
+        }
         if (m > 0) hipLaunchKernelGGL((k_axpby<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (int)m, (T)rho, z, T(-1), y, w);   // :176
         {
             ProfScope ps(prof, cat_spmv, 2);
@@ -636,17 +686,23 @@ template <typename T> struct SparseSolver : SolverBase {
         eps_pcg = p.epsPcg; itr_pcg = p.numItrPcg;
         const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;
         int convFlag = QPS_CONV_NUM_ITR;
+        plugin_kind = (p.linsys == QPS_LINSYS_KKT_LDL) ? QPS_LINSYS_KKT_LDL : QPS_LINSYS_CG;
+        if (p.linsys == QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
+        if (plugin_kind == QPS_LINSYS_KKT_LDL) ldl_prepare(rho, sigma, !p.reuseFactor);             // SolveQuadraticProgram.jl:36 LinSysSolInit
         upload_vec(xh, x, n);
         const size_t nb_ = sizeof(T) * (size_t)(n + 64), mb_ = sizeof(T) * (size_t)(m + 64);
         HIPC(hipMemsetAsync(xp, 0, nb_, st)); HIPC(hipMemsetAsync(xx, 0, nb_, st));                 // LinOpCgInit: vXX = zeros (:147)
         HIPC(hipMemsetAsync(z, 0, mb_, st)); HIPC(hipMemsetAsync(y, 0, mb_, st)); HIPC(hipMemsetAsync(zp, 0, mb_, st));
         HIPC(hipStreamSynchronize(st));
         const double t1 = now_s();
-        double rhorho = rho; int ii = 0, nref = 0; double resP = NAN, resD = NAN;
+        double rhorho = rho; int ii = 0, nref = 0; double resP = NAN, resD = NAN, tref = 0;
         cg_total = 0; last_cg = 4;
         const int NPv = (int)n, MPv = (int)m;
         for (ii = 1; ii <= p.numIterations; ++ii) {
-            if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) { rho = rhorho; ++nref; }   // operator is matrix-free: nothing to rebuild
+            if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {
+                rho = rhorho; ++nref;                                                               // CG: the operator is matrix-free, nothing to rebuild
+                if (plugin_kind == QPS_LINSYS_KKT_LDL) { const double ta = now_s(); ldl_prepare(rho, sigma, true); tref += now_s() - ta; }   // changedΡ: numeric refactor only
+            }
             linear_solve(rho, sigma);
             {
                 ProfScope ps(prof, cat_vec, 2);
@@ -678,7 +734,7 @@ template <typename T> struct SparseSolver : SolverBase {
         if (info) {
             info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
             info->numRefactor = nref; info->cgIterations = (int)cg_total; info->rhoFinal = rho; info->rhoProposed = rhorho;
-            info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = 0;
+            info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = tref;
             info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
         }
     }
@@ -709,14 +765,21 @@ template <typename T> struct SparseSolver : SolverBase {
             rep->numActiveLower = pr.numLower; rep->numActiveUpper = pr.numUpper; rep->reserved0 = 0; rep->relres = pr.relres; rep->seconds = pr.seconds;
         }
     }
-    void linsys_init(double, double, int linsys, int) override {
+    void linsys_init(double rho, double sigma, int linsys, int) override {
         HIPC(hipSetDevice(device));
-        if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG) throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles support QPS_LINSYS_CG only (create with dense_path=1 for the Cholesky path)");
+        if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG && linsys != QPS_LINSYS_KKT_LDL)
+            throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
+        plugin_kind = (linsys == QPS_LINSYS_KKT_LDL) ? QPS_LINSYS_KKT_LDL : QPS_LINSYS_CG;
+        if (plugin_kind == QPS_LINSYS_KKT_LDL) { ldl_prepare(rho, sigma, true); return; }            // LinearSystemSolvers.jl:18 / :49 / :81
         HIPC(hipMemsetAsync(xx, 0, sizeof(T) * (size_t)(n + 64), st));                              // LinOpCgInit (:147)
         cg_total = 0; last_cg = 4;
     }
-    void linsys_solve(const double* xh, const double* zh, const double* yh, double rho, double sigma, int, double* xxh, double* zzh) override {
+    void linsys_solve(const double* xh, const double* zh, const double* yh, double rho, double sigma, int changed, double* xxh, double* zzh) override {
         HIPC(hipSetDevice(device));
+        if (plugin_kind == QPS_LINSYS_KKT_LDL) {
+            if (!ldl) throw QpsError(QPS_ERR_BAD_ARGUMENT, "qps_linsys_solve called before qps_linsys_init");
+            if (changed) ldl_prepare(rho, sigma, true);                                             // :30-32 / :61-63 / :93-95
+        }
         upload_vec(xh, x, n); upload_vec(zh, z, m); upload_vec(yh, y, m);
         linear_solve(rho, sigma);
         HIPC(hipStreamSynchronize(st));

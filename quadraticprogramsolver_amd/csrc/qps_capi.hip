@@ -3,6 +3,7 @@
 // Loop structure follows SolveQuadraticProgram.jl:36-73; the linear solve is the reduced form of
 // LinearSystemSolvers.jl:110-142 with cg! replaced by Cholesky + two triangular sweeps (ProxQP.jl:175-206,221-225).
 // There is NO CPU fallback: without a HIP device every entry point fails with QPS_ERR_NO_DEVICE.
+#include "ldl_symbolic.h"
 #include "qps_internal.h"
 #include "qps_kernels.h"
 #include "qps_polish.h"
@@ -275,6 +276,8 @@ template <typename T> struct DenseSolver : SolverBase {
 
     void solve(double* xh, const qps_params& p, qps_info* info) override {
         HIPC(hipSetDevice(device));
+        if (p.linsys != QPS_LINSYS_AUTO && p.linsys != QPS_LINSYS_CHOLESKY)
+            throw QpsError(QPS_ERR_UNSUPPORTED, "dense handles offer QPS_LINSYS_CHOLESKY only (qps_create_csc with dense_path = 0 for the CG and the sparse L D L' plugins)");
         const double t0 = now_s();
         nb = pick_nb(p.trsvBlock, NP);
         double rho = p.rho, sigma = p.sigma; const double alpha = p.alpha;
@@ -1141,6 +1144,36 @@ QPS_API int32_t qps_proxqp_solve(qps_handle hh, const qps_proxqp_params* p, qps_
     if (p->numIterations < 0 || p->numItrConv <= 0 || !(p->rho > 0) || !(p->sigma >= 0) || !(p->tau > 0))
         return fail_with(h, QPS_ERR_BAD_ARGUMENT, "need numIterations >= 0, numItrConv > 0, rho > 0, sigma >= 0, tau > 0");
     return guarded(h, [&] { h->proxqp->solve(*p, rep); });
+}
+
+QPS_API int32_t qps_linsys_auto(int64_t n, int64_t m, int64_t nnzP, int64_t nnzA, int32_t sparse_input) {
+    // SolveQuadraticProgram.jl:129-130 MAX_NUM_ROWS_L = 5000, MAX_DENSITY = 0.4; :143-151 (SolveQuadraticProgram.m:190-199)
+    const double numRowsL = (double)n + (double)m;
+    const double nnzDensity = ((double)nnzP + (double)nnzA) / (numRowsL * numRowsL);
+    const bool directSol = (numRowsL <= 5000.0) && (nnzDensity <= 0.4);
+    if (!directSol) return QPS_LINSYS_CG;
+    return sparse_input ? QPS_LINSYS_KKT_LDL : QPS_LINSYS_CHOLESKY;
+}
+
+QPS_API int32_t qps_ldl_analyze(int64_t n, int64_t m, const int64_t* Pcp, const int64_t* Pri, const int64_t* Acp, const int64_t* Ari,
+                                int32_t index_base, int64_t* perm_out, qps_ldl_report* rep) {
+    if (n <= 0 || m < 0 || n + m > 2000000000LL) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1, m >= 0, n + m < 2^31");
+    if (!Pcp || !Acp || (!Pri && Pcp[n] > index_base) || (!Ari && Acp[n] > index_base)) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL index array");
+    if (index_base != 0 && index_base != 1) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "index_base must be 0 or 1");
+    for (int64_t j = 0; j < n; ++j) if (Pcp[j + 1] < Pcp[j] || Acp[j + 1] < Acp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr not monotone");
+    for (int64_t k = 0; k < Pcp[n] - index_base; ++k) if (Pri[k] - index_base < 0 || Pri[k] - index_base >= n) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "P row index out of range");
+    for (int64_t k = 0; k < Acp[n] - index_base; ++k) if (Ari[k] - index_base < 0 || Ari[k] - index_base >= m) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "A row index out of range");
+    return guarded(nullptr, [&] {
+        const char* e1 = getenv("QPS_LDL_MAX_TAIL"); const char* e2 = getenv("QPS_LDL_MIN_LEVEL"); const char* e3 = getenv("QPS_LDL_MAX_LEVELS");
+        LdlSymbolic s;
+        try { s = ldl_analyze((int)n, (int)m, Pcp, Pri, Acp, Ari, index_base, e1 ? atoi(e1) : 8192, e2 ? atoi(e2) : 64, e3 ? atoi(e3) : 4096); }
+        catch (const std::runtime_error& e) { throw QpsError(QPS_ERR_UNSUPPORTED, e.what()); }
+        if (perm_out) for (int64_t k = 0; k < n + m; ++k) perm_out[k] = (int64_t)s.perm[k] + index_base;
+        if (rep) {
+            rep->numRows = s.N; rep->numSparseColumns = s.Ns; rep->tailSize = s.Nt; rep->numSparseLevels = (int64_t)s.level_ptr.size() - 1;
+            rep->treeHeight = s.levels_total; rep->nnzK = s.nnzK; rep->nnzL = s.nnzL_exact; rep->nnzStored = s.nnzL;
+        }
+    });
 }
 
 QPS_API int32_t qps_destroy(qps_handle hh) {

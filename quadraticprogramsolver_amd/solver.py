@@ -23,7 +23,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import QPS_F32, QPS_F64, QPS_LINSYS_AUTO, QPS_LINSYS_CG, QPS_LINSYS_CHOLESKY, QpsInfo
+from ._lib import QPS_F32, QPS_F64, QPS_LINSYS_AUTO, QPS_LINSYS_CG, QPS_LINSYS_CHOLESKY, QPS_LINSYS_KKT_LDL, QpsInfo
 
 
 class LinearSolverMode(enum.IntEnum):
@@ -73,7 +73,8 @@ def _validate_dims(numElementsX, mP, vQ, mA, vL, vU):
 class QuadraticProgram:
     """A problem resident in HBM (qps_create_dense / qps_create_csc ... qps_destroy).
 
-    ``linsys``: "cholesky" (dense reduced form; sparse inputs are densified on the device) or "cg" (CSR, matrix-free).
+    ``linsys``: "cholesky" (dense reduced form; sparse inputs are densified on the device), "cg" (CSR, matrix-free CG on the
+    reduced operator) or "ldl" (CSR, sparse L D L' of the KKT matrix: the reference's direct plugins).
     """
 
     def __init__(self, mP, vQ, mA, vL, vU, *, linsys="cholesky", dtype="f64", device=0):
@@ -81,12 +82,13 @@ class QuadraticProgram:
         m = mA.shape[0]
         _validate_dims(n, mP, vQ, mA, vL, vU)
         self.n, self.m = n, m
-        self.linsys = {"cholesky": QPS_LINSYS_CHOLESKY, "cg": QPS_LINSYS_CG, "auto": QPS_LINSYS_AUTO}[linsys]
+        self.linsys = {"cholesky": QPS_LINSYS_CHOLESKY, "cg": QPS_LINSYS_CG, "ldl": QPS_LINSYS_KKT_LDL, "auto": QPS_LINSYS_AUTO}[linsys]
+        csr = linsys in ("cg", "ldl")
         dt = {"f64": QPS_F64, "f32": QPS_F32}[dtype]
         q, l, u = _vec(vQ, "vQ", n), _vec(vL, "vL", m), _vec(vU, "vU", m)
         h = C.c_void_p()
         L = _lib.lib()
-        if sp.issparse(mP) or sp.issparse(mA) or linsys == "cg":
+        if sp.issparse(mP) or sp.issparse(mA) or csr:
             Pc = sp.csc_matrix(mP, dtype=np.float64)
             Ac = sp.csc_matrix(mA, dtype=np.float64)
             Pc.sum_duplicates()
@@ -94,7 +96,7 @@ class QuadraticProgram:
             Pcp, Pri, Pnz = Pc.indptr.astype(np.int64), Pc.indices.astype(np.int64), np.ascontiguousarray(Pc.data)
             Acp, Ari, Anz = Ac.indptr.astype(np.int64), Ac.indices.astype(np.int64), np.ascontiguousarray(Ac.data)
             st = L.qps_create_csc(n, m, _ip(Pcp), _ip(Pri), _dp(Pnz), _ip(Acp), _ip(Ari), _dp(Anz), _dp(q), _dp(l), _dp(u),
-                                  0, 0 if linsys == "cg" else 1, dt, device, C.byref(h))
+                                  0, 0 if csr else 1, dt, device, C.byref(h))
         else:
             Pd = np.asfortranarray(mP, dtype=np.float64)
             Ad = np.asfortranarray(mA, dtype=np.float64)
@@ -266,6 +268,7 @@ def _make_pair(linsys: str, dtype: str = "f64"):
 
 HipCholInit, HipChol = _make_pair("cholesky")
 HipCgInit, HipCg = _make_pair("cg")
+HipLdlInit, HipLdl = _make_pair("ldl")          # sparse L D L' of the KKT matrix: LaLdl / QDLdl / FacLdl (LinearSystemSolvers.jl:16-107)
 HipCholF32Init, HipCholF32 = _make_pair("cholesky", "f32")
 
 
@@ -281,7 +284,7 @@ def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholIn
     linsys = getattr(LinSysSolInit, "_qps_linsys", None)
     if linsys is None or getattr(LinSysSol, "_qps_linsys", None) != linsys:
         raise TypeError("LinSysSolInit/LinSysSol must be one of this package's pairs (HipCholInit, HipChol) / "
-                        "(HipCgInit, HipCg): the device-resident loop has no CPU path")
+                        "(HipCgInit, HipCg) / (HipLdlInit, HipLdl): the device-resident loop has no CPU path")
     with QuadraticProgram(mP, vQ, mA, vL, vU, linsys=linsys, dtype=LinSysSolInit._qps_dtype, device=device) as prob:
         return prob.solve(vX, numIterations=numIterations, ϵAbs=ϵAbs, ϵRel=ϵRel, ρ=ρ, σ=σ, α=α, δ=δ, adptΡ=adptΡ,
                           fctrΡ=fctrΡ, numItrConv=numItrConv, numItrPolish=numItrPolish, ϵMinres=ϵMinres,
@@ -291,16 +294,33 @@ def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholIn
 SolveQuadraticProgram_b = SolveQuadraticProgramInplace
 
 
+def AutoLinearSolverMode(mP, mA):
+    """The ``modeAuto`` rule of the reference (SolveQuadraticProgram.jl:129-130, :143-151; SolveQuadraticProgram.m:190-199),
+    literally: direct when ``numRowsL = rows(P) + rows(A) <= 5000`` and ``(nnz(P) + nnz(A)) / numRowsL^2 <= 0.4``, else iterative.
+    Evaluated by the library (``qps_linsys_auto``) so that every binding shares one rule.  ``nnz`` of a dense array counts its
+    non-zero entries, as Julia's / MATLAB's ``nnz`` does."""
+    nnz = lambda M: int(M.nnz) if sp.issparse(M) else int(np.count_nonzero(M))
+    kind = _lib.lib().qps_linsys_auto(mP.shape[0], mA.shape[0], nnz(mP), nnz(mA), int(sp.issparse(mP) and sp.issparse(mA)))
+    return LinearSolverMode.modeItertaive if kind == QPS_LINSYS_CG else LinearSolverMode.modeDirect
+
+
 def SolveQuadraticProgram(mP, vQ, mA, vL, vU, *, linearSolverMode=LinearSolverMode.modeAuto, **kw):
     """Convenience form spelled in BASELINE.json's north_star: ``SolveQuadraticProgram(P, q, A, l, u; ...) -> (x, flag)``.
 
-    ``modeAuto`` follows the reference rule (SolveQuadraticProgram.jl:143-151: direct when the problem is small and not
-    too dense) re-scaled for HBM: dense Cholesky while the n x n factor is cheap to hold, CSR/CG beyond."""
+    ``linearSolverMode`` (SolveQuadraticProgram.jl:11): ``modeDirect`` = a factorisation on the device -- the sparse L D L' of the
+    KKT matrix when both matrices are scipy-sparse (what the reference's direct branch does, :168-172), the dense reduced Cholesky
+    otherwise; ``modeItertaive`` = matrix-free CG (:153-157); ``modeAuto`` = the reference's size / density rule (see
+    ``AutoLinearSolverMode``).  Note that the rule was tuned for a CPU: it sends every problem with more than 5000 rows -- BASELINE's
+    dense n = 4096, m = 8192 included -- to CG; pass ``modeDirect`` (or a plugin pair to ``SolveQuadraticProgramInplace``) to keep
+    such a problem on the factorisation path."""
     mode = LinearSolverMode(linearSolverMode)
     n = mP.shape[0]
     if mode == LinearSolverMode.modeAuto:
-        mode = LinearSolverMode.modeDirect if n <= 16384 else LinearSolverMode.modeItertaive
-    pair = (HipCholInit, HipChol) if mode == LinearSolverMode.modeDirect else (HipCgInit, HipCg)
+        mode = AutoLinearSolverMode(mP, mA)
+    if mode == LinearSolverMode.modeDirect:
+        pair = (HipLdlInit, HipLdl) if (sp.issparse(mP) and sp.issparse(mA)) else (HipCholInit, HipChol)
+    else:
+        pair = (HipCgInit, HipCg)
     vX = np.zeros(n)
     flag = SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, *pair, **kw)
     return vX, flag

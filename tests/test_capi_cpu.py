@@ -106,6 +106,71 @@ def test_asymmetric_p_is_refused_like_issymmetric(qps):
             assert e.value.status == 7
 
 
+def test_mode_auto_rule_is_the_reference_rule(qps):
+    """SolveQuadraticProgram.jl:129-130, :143-151 (SolveQuadraticProgram.m:190-199): direct iff rows(P) + rows(A) <= 5000 and
+    (nnz(P) + nnz(A)) / rows^2 <= 0.4 -- evaluated by the library, no device needed."""
+    from quadraticprogramsolver_amd import _lib
+    L = _lib.lib()
+    CG, CHOL, LDL = _lib.QPS_LINSYS_CG, _lib.QPS_LINSYS_CHOLESKY, _lib.QPS_LINSYS_KKT_LDL
+    assert L.qps_linsys_auto(1000, 500, 150000, 75000, 1) == LDL            # 1500 rows, density 0.1
+    assert L.qps_linsys_auto(1000, 500, 150000, 75000, 0) == CHOL           # same problem held as dense arrays
+    assert L.qps_linsys_auto(3000, 2000, 10, 10, 1) == LDL                  # exactly 5000 rows: still direct (<=)
+    assert L.qps_linsys_auto(3000, 2001, 10, 10, 1) == CG                   # 5001 rows
+    assert L.qps_linsys_auto(100, 100, 16000, 0, 1) == LDL                  # density exactly 0.4
+    assert L.qps_linsys_auto(100, 100, 16001, 0, 1) == CG
+    assert L.qps_linsys_auto(4096, 8192, 4096 * 4096, 4096 * 8192, 0) == CG  # BASELINE's dense config by the literal rule
+    import scipy.sparse as sp
+    assert qps.AutoLinearSolverMode(sp.eye(100, format="csc"), sp.eye(100, format="csc")) == qps.LinearSolverMode.modeDirect
+    assert qps.AutoLinearSolverMode(np.ones((100, 100)), np.ones((50, 100))) == qps.LinearSolverMode.modeItertaive
+
+
+def _analyze(P, A, base=0):
+    import scipy.sparse as sp
+    from quadraticprogramsolver_amd import _lib
+    Pc, Ac = sp.csc_matrix(P), sp.csc_matrix(A)
+    Pc.sum_duplicates(); Ac.sum_duplicates()
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    arrs = [np.ascontiguousarray(a.astype(np.int64) + base) for a in (Pc.indptr, Pc.indices, Ac.indptr, Ac.indices)]
+    perm = np.zeros(P.shape[0] + A.shape[0], dtype=np.int64)
+    rep = _lib.QpsLdlReport()
+    _lib.check(_lib.lib().qps_ldl_analyze(P.shape[0], A.shape[0], ip(arrs[0]), ip(arrs[1]), ip(arrs[2]), ip(arrs[3]), base, ip(perm), C.byref(rep)))
+    return perm - base, rep.as_dict()
+
+
+def _symbolic_nnz(K, perm):
+    """Independent count of nnz(L) (strictly lower) for the ordering `perm`: boolean elimination on the permuted pattern."""
+    N = K.shape[0]
+    B = (K[perm][:, perm].toarray() != 0)
+    B = B | B.T
+    cnt = 0
+    for k in range(N):
+        rows = np.nonzero(B[k + 1:, k])[0] + k + 1
+        cnt += rows.size
+        if rows.size:
+            B[np.ix_(rows, rows)] = True
+    return cnt
+
+
+@pytest.mark.parametrize("pc,n", [("randomQp", 30), ("equalityConstrainedQp", 40), ("portfolioOptimization", 100), ("lassoOptimization", 6),
+                                  ("huberFitting", 4), ("supportVectorMachine", 6), ("isotonicRegression", 60)])
+def test_ldl_symbolic_analysis(qps, pc, n):
+    """The host half of QPS_LINSYS_KKT_LDL (ordering, elimination tree, symbolic factor) runs without a device: the ordering is a
+    permutation, the predicted nnz(L) equals an independent boolean elimination under that ordering, the minimum-degree ordering
+    beats the natural one, the level / tail split covers every column, and the 1-based (Julia) entry gives the same answer."""
+    import scipy.sparse as sp
+    P, q, A, l, u = qps.GenerateRandomQP(getattr(qps.ProblemClass, pc), n, rng=qps.make_rng(31, n))
+    nn, m = P.shape[0], A.shape[0]
+    perm, rep = _analyze(P, A)
+    assert sorted(perm.tolist()) == list(range(nn + m))
+    K = sp.bmat([[sp.csc_matrix(P) + sp.eye(nn), sp.csc_matrix(A).T], [sp.csc_matrix(A), -sp.eye(m)]], format="csr")
+    assert rep["nnzL"] == _symbolic_nnz(K, perm)
+    assert rep["nnzL"] <= _symbolic_nnz(K, np.arange(nn + m))
+    assert rep["numRows"] == nn + m == rep["numSparseColumns"] + rep["tailSize"]
+    assert rep["nnzK"] == sp.tril(K, -1).nnz and rep["nnzStored"] >= rep["nnzL"] >= rep["nnzK"]
+    perm1, rep1 = _analyze(P, A, base=1)
+    assert np.array_equal(perm, perm1) and rep == rep1
+
+
 def test_fails_loudly_without_a_gpu(qps):
     from quadraticprogramsolver_amd import _lib
     if _lib.lib().qps_device_count() > 0:
@@ -113,7 +178,11 @@ def test_fails_loudly_without_a_gpu(qps):
     P, q, A, l, u = np.eye(4), np.zeros(4), np.ones((3, 4)), -np.ones(3), np.ones(3)
     with pytest.raises(qps.QpsError) as e:
         qps.SolveQuadraticProgram(P, q, A, l, u)
-    assert e.value.status == 7 and "no CPU fallback" in str(e.value)
+    assert e.value.status == 7
+    for pair in ((qps.HipCholInit, qps.HipChol), (qps.HipCgInit, qps.HipCg), (qps.HipLdlInit, qps.HipLdl)):
+        with pytest.raises(qps.QpsError) as e:
+            qps.SolveQuadraticProgramInplace(np.zeros(4), P, q, A, l, u, *pair)
+        assert e.value.status == 7 and "no CPU fallback" in str(e.value)
 
 
 def test_proxqp_defaults_are_the_reference_defaults(qps):

@@ -1,0 +1,177 @@
+"""GPU parity of the sparse direct KKT plugin (QPS_LINSYS_KKT_LDL; HipLdlInit / HipLdl) -- the counterpart of the plugin the
+reference's own tests and benchmarks select: FacLdlInit / FacLdl! (RunTests.jl:55-56, RunBenchmarks.jl:54-55), QDLdlInit / QDLdl!
+(SolveQuadraticProgramUnitTest.jl:65-66), LaLdlInit / LaLdl! (LinearSystemSolvers.jl:16-107).
+
+Oracle: the C restatement with its sparse CSC L D L' plugin (QDLDL's published algorithm, oracle/qps_oracle.c kind 4; ordering from
+SuperLU's MMD, i.e. shared with nothing in the product), itself checked against the dense KKT oracle in tests/test_oracle.py.
+Tolerances: iterate level 1e-9 relative where K is well conditioned (classes 1-4, 9); the lasso / Huber / SVM / portfolio classes
+have zero blocks in P, so K carries pivots of size sigma = 1e-6 and two correct factorisations with different orderings differ by
+~1e-16 * cond(K) ~ 1e-8 (the sparse and the dense KKT ORACLES differ by 7e-9 on them): 1e-6 there; solution level 1e-5
+(RunTests.jl:58) with the oracle's flag, iteration and re-factorisation counts everywhere."""
+import os
+import time
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from quadraticprogramsolver_amd.generator import GenerateRandomQP, ProblemClass, make_rng
+
+pytestmark = pytest.mark.gpu
+ABS_DEV_THR = 1e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ILL = (ProblemClass.portfolioOptimization, ProblemClass.lassoOptimization, ProblemClass.huberFitting, ProblemClass.supportVectorMachine)
+
+
+def note(line):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "ldl_parity.log"), "a") as f:
+        f.write(line + "\n")
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max()) if b.size else 0.0
+
+
+def kkt(P, A, rho, sigma):
+    n, m = P.shape[0], A.shape[0]
+    return sp.bmat([[sp.csc_matrix(P) + sigma * sp.eye(n), sp.csc_matrix(A).T], [sp.csc_matrix(A), -sp.eye(m) / rho]], format="csc")
+
+
+PAIR_CASES = [(ProblemClass.randomQp, 100), (ProblemClass.equalityConstrainedQp, 100), (ProblemClass.portfolioOptimization, 100),
+              (ProblemClass.lassoOptimization, 20), (ProblemClass.huberFitting, 10), (ProblemClass.supportVectorMachine, 20),
+              (ProblemClass.isotonicRegression, 300), (ProblemClass.randomQp, 10), (ProblemClass.inequalityConstrainedQp, 120)]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("pc,n", PAIR_CASES)
+def test_ldl_plugin_pair_in_isolation(gpu, pc, n, dtype):
+    """LinSysSolInit / LinSysSol! of the direct plugins (LinearSystemSolvers.jl:16-44): K [x~; nu] = [sigma x - q; z - y / rho],
+    z~ = z + (nu - y) / rho, including the changedRho re-factorisation -- against SuperLU on the same K."""
+    P, q, A, l, u = GenerateRandomQP(pc, n, rng=make_rng(77, int(pc)))
+    nn, m = P.shape[0], A.shape[0]
+    rng = make_rng(78, int(pc))
+    sigma = 1e-6
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="ldl", dtype=dtype) as prob:
+        prob.linsys_init(0.3, sigma)
+        for changed, rho in ((False, 0.3), (True, 40.0), (False, 40.0), (True, 1e-3)):
+            x, z, y = rng.standard_normal(nn), rng.standard_normal(m), rng.standard_normal(m)
+            xx, zz = np.zeros(nn), np.zeros(m)
+            prob.linsys_solve(x, z, y, rho, sigma, changed, xx, zz)
+            sol = spla.splu(kkt(P, A, rho, sigma)).solve(np.concatenate([sigma * x - q, z - y / rho]))
+            zr = z + (sol[nn:] - y) / rho
+            tol = (1e-9 if pc not in ILL else 1e-6) if dtype == "f64" else 5e-2
+            if dtype == "f64":
+                assert rel(xx, sol[:nn]) <= tol and rel(zz, zr) <= tol, (pc, rho, rel(xx, sol[:nn]), rel(zz, zr))
+            else:   # fp32: pivots of size sigma = 1e-6 next to O(1) entries -- check the residual of the well-scaled rows instead
+                K = kkt(P, A, rho, sigma)
+                nu = (zz - z) * rho + y
+                r = K @ np.concatenate([xx, nu]) - np.concatenate([sigma * x - q, z - y / rho])
+                assert np.abs(r).max() <= 5e-3 * max(1.0, np.abs(np.concatenate([sigma * x - q, z - y / rho])).max()), (pc, rho, np.abs(r).max())
+
+
+ITER_CASES = [(ProblemClass.randomQp, 100), (ProblemClass.inequalityConstrainedQp, 100), (ProblemClass.equalityConstrainedQp, 100),
+              (ProblemClass.optimalControl, 100), (ProblemClass.portfolioOptimization, 100), (ProblemClass.lassoOptimization, 10),
+              (ProblemClass.huberFitting, 10), (ProblemClass.supportVectorMachine, 10), (ProblemClass.isotonicRegression, 100)]
+
+
+@pytest.mark.parametrize("pc,n", ITER_CASES)
+def test_ldl_iterates_match_oracle_all_classes(gpu, c_oracle, pc, n):
+    m = (n // 2) if pc == ProblemClass.equalityConstrainedQp else 0
+    P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 40 + int(pc)))
+    tol = 1e-9 if pc not in ILL else 1e-6
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="ldl") as prob:
+        for K in (25, 60):
+            x = np.zeros(P.shape[0]); info = {}
+            prob.solve(x, numIterations=K, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+            z, y = prob.dual()
+            xo, io = c_oracle.solve(P, q, A, l, u, numIterations=K, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+            assert rel(x, xo) <= tol and rel(z, io["z"]) <= tol and rel(y, io["y"]) <= 10 * tol, (pc, K, rel(x, xo), rel(z, io["z"]), rel(y, io["y"]))
+            assert abs(info["resPrim"] - io["resPrim"]) <= tol * max(1.0, io["resPrim"])
+            assert abs(info["resDual"] - io["resDual"]) <= 10 * tol * max(1.0, io["resDual"])
+
+
+RUNTESTS_SIZES = {pc: (10, 100) for pc in ProblemClass}                               # RunTests.jl:30-38: every class at both sizes
+
+
+@pytest.mark.parametrize("pc", list(ProblemClass))
+def test_ldl_runtests_sweep(gpu, c_oracle, np_oracle, pc):
+    """RunTests.jl:62-99 with the plugin the reference itself selects there (:55-56 FacLdlInit / FacLdl!): every ProblemClass, both
+    sizes -- lasso / Huber / SVM at numElements = 100 (10 200 / 30 100 / 10 100 variables) included -- numIterations = 50000,
+    eps = 1e-7, rho = 0.1, adptRho; the assertion of :93 with the CPU oracle in OSQP's role."""
+    checked = 0
+    for sim in range(3):
+        for n in RUNTESTS_SIZES[pc]:
+            m = (n // 2) if pc == ProblemClass.equalityConstrainedQp else 0           # RunTests.jl:39-47
+            P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(4321, 1000 * int(pc) + 10 * sim + (n > 10)))
+            xo, io = c_oracle.solve(P, q, A, l, u, numIterations=50000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+            if io["convFlag"] == 1 or (io["convFlag"] == 2 and io["resPrim"] > 1e-4):
+                continue   # infeasible tiny draw: ends by the stall test with rho at its clamp, where the stopping iteration is round-off sensitive
+            x = np.zeros(P.shape[0]); info = {}
+            t0 = time.perf_counter()
+            flag = gpu.SolveQuadraticProgramInplace(x, P, q, A, l, u, gpu.HipLdlInit, gpu.HipLdl, numIterations=50000, ϵAbs=1e-7, ϵRel=1e-7,
+                                                    ρ=0.1, adptΡ=True, info=info)                  # RunTests.jl:85
+            dt = time.perf_counter() - t0
+            dev = np.abs(x - xo).max()
+            note(f"runtests {pc.name} n={n} N={P.shape[0]} M={A.shape[0]} sim={sim}: flag {int(flag)}/{io['convFlag']} iterations {info['iterations']}/{io['iterations']} "
+                 f"refactor {info['numRefactor']}/{io['numRefactor']} max|x-x_oracle| {dev:.2e}; setup {info['tSetup']*1e3:.1f} ms loop {info['tLoop']*1e3:.1f} ms call {dt*1e3:.1f} ms")
+            assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"], (pc, n, sim, info, io["iterations"])
+            assert dev <= ABS_DEV_THR                                                   # RunTests.jl:93
+            checked += 1
+    assert checked >= 3
+
+
+def test_ldl_isotonic_800_unit_test_script(gpu, c_oracle):
+    """SolveQuadraticProgramUnitTest.jl:31-43, :65-66: isotonicRegression, numElements = 800, rho = 0.1, adptRho, the QDLDL plugin.
+    Time-to-eps of the three device plugins side by side (logged, not asserted)."""
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.isotonicRegression, 800, rng=make_rng(1234, 9))
+    kw = dict(numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=5000, epsAbs=1e-6, epsRel=1e-6, rho=0.1, adptRho=True, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+    out = {}
+    for name, pair in (("ldl", (gpu.HipLdlInit, gpu.HipLdl)), ("cholesky", (gpu.HipCholInit, gpu.HipChol)), ("cg", (gpu.HipCgInit, gpu.HipCg))):
+        for rep in range(2):                                                            # second call: warm caches / recycled handles
+            x = np.zeros(800); info = {}
+            t0 = time.perf_counter()
+            flag = gpu.SolveQuadraticProgramInplace(x, P, q, A, l, u, *pair, info=info, **kw)
+            out[name] = (x, int(flag), info, time.perf_counter() - t0)
+        note(f"isotonic n=800 {name}: flag {out[name][1]} iterations {info['iterations']} refactor {info['numRefactor']} setup {info['tSetup']*1e3:.2f} ms "
+             f"loop {info['tLoop']*1e3:.2f} ms whole call {out[name][3]*1e3:.2f} ms max|x-x_oracle| {np.abs(x - xo).max():.2e}")
+    x, flag, info, _ = out["ldl"]
+    assert flag == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+    assert np.abs(x - xo).max() <= ABS_DEV_THR
+    assert np.abs(out["cholesky"][0] - xo).max() <= ABS_DEV_THR
+
+
+def test_mode_auto_follows_the_reference_rule(gpu, c_oracle):
+    """SolveQuadraticProgram.jl:143-151: direct when n + m <= 5000 and the density is <= 0.4, else iterative.  Both branches are
+    reached through `linearSolverMode = modeAuto` and solve to the reference tolerance."""
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.randomQp, 200, rng=make_rng(5, 1))          # sparse, 300 rows, density 0.25: direct -> L D L'
+    assert gpu.AutoLinearSolverMode(P, A) == gpu.LinearSolverMode.modeDirect
+    x, flag = gpu.SolveQuadraticProgram(P, q, A, l, u, numIterations=20000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
+    assert int(flag) == io["convFlag"] and np.abs(x - xo).max() <= ABS_DEV_THR
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.randomQp, 4000, numConstraints=2000, densityFctr=0.003, rng=make_rng(5, 2))   # 6000 rows: iterative
+    assert gpu.AutoLinearSolverMode(P, A) == gpu.LinearSolverMode.modeItertaive
+    info = {}
+    x, flag = gpu.SolveQuadraticProgram(P, q, A, l, u, numIterations=4000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True, info=info)
+    assert info["cgIterations"] > 0 and int(flag) in (2, 3)
+    xd, fd = gpu.SolveQuadraticProgram(P, q, A, l, u, linearSolverMode=gpu.LinearSolverMode.modeDirect, numIterations=4000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
+    assert int(fd) == int(flag) and np.abs(x - xd).max() <= 1e-4 * max(1.0, np.abs(xd).max())
+    # dense n = 64, m = 128: 192 rows but density 1 > 0.4 -> iterative by the literal rule
+    from quadraticprogramsolver_amd.generator import GenerateDenseBenchmarkQP
+    Pd, qd, Ad, ld, ud = GenerateDenseBenchmarkQP(64, 128, stream=3, feasible=True)
+    assert gpu.AutoLinearSolverMode(Pd, Ad) == gpu.LinearSolverMode.modeItertaive
+
+
+def test_ldl_refuses_what_it_cannot_hold(gpu):
+    """A dense handle has no sparse KKT plugin; the error is explicit (no silent fall back to another plugin)."""
+    from quadraticprogramsolver_amd import _lib
+    import ctypes as C
+    P, q, A, l, u = np.eye(8), np.zeros(8), np.ones((2, 8)), -np.ones(2), np.ones(2)
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        prob.linsys = _lib.QPS_LINSYS_KKT_LDL
+        with pytest.raises(gpu.QpsError) as e:
+            prob.solve(np.zeros(8))
+        assert e.value.status == 8

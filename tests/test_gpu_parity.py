@@ -53,7 +53,7 @@ def test_golden_solutions(gpu, name, variant):
 @pytest.mark.parametrize("kat", ["unconstrained", "equality", "box_diag"])
 def test_known_answers(gpu, kat, n):
     g = load_golden(f"kat_{kat}_n{n}")
-    x, flag = gpu.SolveQuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"], **REF_KW)
+    x, flag = gpu.SolveQuadraticProgram(g["P"], g["q"], g["A"], g["l"], g["u"], linearSolverMode=gpu.LinearSolverMode.modeDirect, **REF_KW)
     assert int(flag) in (2, 3)
     assert np.abs(x - g["x_star"]).max() <= ABS_DEV_THR
 
@@ -149,10 +149,10 @@ def test_edge_cases(gpu, c_oracle):
     n = 8
     M = rng.standard_normal((n, n)); P = M.T @ M + np.eye(n); q = rng.standard_normal(n)
     # no constraints at all (empty A, l, u)
-    x, flag = gpu.SolveQuadraticProgram(P, q, np.zeros((0, n)), np.zeros(0), np.zeros(0), numIterations=5000, ϵAbs=1e-9, ϵRel=1e-9)
+    x, flag = gpu.SolveQuadraticProgram(P, q, np.zeros((0, n)), np.zeros(0), np.zeros(0), linearSolverMode=gpu.LinearSolverMode.modeDirect, numIterations=5000, ϵAbs=1e-9, ϵRel=1e-9)
     assert np.abs(x - np.linalg.solve(P, -q)).max() <= 1e-6
     # n = 1
-    x, flag = gpu.SolveQuadraticProgram(np.array([[2.0]]), np.array([-4.0]), np.array([[1.0]]), np.array([-1.0]), np.array([1.0]), **REF_KW)
+    x, flag = gpu.SolveQuadraticProgram(np.array([[2.0]]), np.array([-4.0]), np.array([[1.0]]), np.array([-1.0]), np.array([1.0]), linearSolverMode=gpu.LinearSolverMode.modeDirect, **REF_KW)
     assert abs(x[0] - 1.0) <= ABS_DEV_THR
     # warm start is honoured for x and z, y restart at 0 (SolveQuadraticProgram.jl:39-40)
     g = load_golden("c1_randomQp_n64_m32")
@@ -173,13 +173,13 @@ def test_error_behaviour(gpu):
     n = 70
     P = -np.eye(n); A = np.zeros((1, n)); A[0, 0] = 1.0
     with pytest.raises(gpu.QpsError) as e:
-        gpu.SolveQuadraticProgram(P, np.zeros(n), A, np.array([-1.0]), np.array([1.0]))
+        gpu.SolveQuadraticProgram(P, np.zeros(n), A, np.array([-1.0]), np.array([1.0]), linearSolverMode=gpu.LinearSolverMode.modeDirect)
     assert e.value.status == 4 and "pivot" in str(e.value)
     with pytest.raises(gpu.QpsError) as e:
         gpu.QuadraticProgram(np.full((3, 3), np.nan), np.zeros(3), np.zeros((1, 3)), np.zeros(1), np.zeros(1))
     assert e.value.status == 3
     with pytest.raises(gpu.QpsError):
-        gpu.SolveQuadraticProgram(np.eye(3), np.zeros(3), np.eye(3), -np.ones(3), np.ones(3), ρ=-1.0)
+        gpu.SolveQuadraticProgram(np.eye(3), np.zeros(3), np.eye(3), -np.ones(3), np.ones(3), linearSolverMode=gpu.LinearSolverMode.modeDirect, ρ=-1.0)
 
 
 def test_fp32_path(gpu, c_oracle):

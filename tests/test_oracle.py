@@ -212,3 +212,27 @@ def test_against_third_party_solver(c_oracle, pc, n, m, dense):
                        method="trust-constr", constraints=[LinearConstraint(Ad, l, u)],
                        options=dict(gtol=1e-10, xtol=1e-12, barrier_tol=1e-12, maxiter=5000))
     assert np.abs(res.x - x).max() <= ABS_DEV_THR
+
+
+@pytest.mark.parametrize("pc,n", [("randomQp", 40), ("equalityConstrainedQp", 60), ("portfolioOptimization", 100), ("isotonicRegression", 50),
+                                  ("lassoOptimization", 4), ("supportVectorMachine", 4)])
+def test_sparse_ldl_oracle_equals_dense_kkt_oracle(c_oracle, pc, n):
+    """The oracle's sparse CSC L D L' plugin (QDLDL's published algorithm: elimination tree, column counts, up-looking numeric
+    factorisation; LinearSystemSolvers.jl:47-75) against its dense KKT plugin on the same problems: same iterates, and with adaptive
+    rho the same flags, iteration and re-factorisation counts -- for the SuperLU-MMD ordering and for the natural one."""
+    from quadraticprogramsolver_amd.generator import GenerateRandomQP, ProblemClass, make_rng
+    P, q, A, l, u = GenerateRandomQP(getattr(ProblemClass, pc), n, rng=make_rng(1, n))
+    tol = 1e-10 if pc in ("randomQp", "equalityConstrainedQp", "isotonicRegression") else 1e-6   # zero blocks in P: pivots of size sigma
+    N = P.shape[0] + A.shape[0]
+    for perm in (None, np.arange(N)):
+        xa, ia = c_oracle.solve(P, q, A, l, u, numIterations=60, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_KKT_LDL)
+        xb, ib = c_oracle.solve(P, q, A, l, u, numIterations=60, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_KKT_LDL_SPARSE, perm=perm)
+        assert np.abs(xa - xb).max() <= tol * max(1.0, np.abs(xa).max()) and np.abs(ia["y"] - ib["y"]).max() <= 10 * tol * max(1.0, np.abs(ia["y"]).max())
+    kw = dict(numIterations=20000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
+    xa, ia = c_oracle.solve(P, q, A, l, u, linsys=c_oracle.KIND_KKT_LDL, **kw)
+    xb, ib = c_oracle.solve(P, q, A, l, u, linsys=c_oracle.KIND_KKT_LDL_SPARSE, **kw)
+    assert (ia["iterations"], ia["numRefactor"]) == (ib["iterations"], ib["numRefactor"])
+    # (at the final check of a tiny problem the stall test |dx| <= 1e-9 can sit within round-off of the 7e-9 the two factorisations
+    # differ by on the sigma-regularised classes: convAdmm overrides convPrimDual on one side only)
+    assert ia["convFlag"] == ib["convFlag"] or (tol > 1e-9 and {ia["convFlag"], ib["convFlag"]} == {2, 3})
+    assert np.abs(xa - xb).max() <= 1e-7
