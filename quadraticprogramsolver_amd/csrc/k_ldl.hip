@@ -96,11 +96,12 @@ __global__ __launch_bounds__(256) void k_ldl_densify(int e0, int e1, const int* 
     const int q = ent_q[e]; const T v = vc[q];
     Ld[ent_dst[e]] = v; Wd[ent_dst[e]] = v * D[cj[q]];
 }
-// rows of the lower triangle (diagonal included) of the tail's sweep matrix scaled by the pivot signs: forward sweep then yields J W t
+// u <- J u between the two sweeps of a tail with constraint rows in it (K_tt = Lt J Lt': x = inv(Lt)' J inv(Lt) t).  The signs
+// cannot live in the sweep matrix: its diagonal is shared by the lower (forward) and the upper (backward) triangle.
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_sign_rows(int ldt, const T* __restrict__ sgn, T* __restrict__ S) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (j <= i && j < ldt && sgn[i] < T(0)) S[(int64_t)i * ldt + j] = -S[(int64_t)i * ldt + j];
+__global__ __launch_bounds__(256) void k_ldl_mul_sign(int ldt, const T* __restrict__ sgn, T* __restrict__ u) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ldt && sgn[i] < T(0)) u[i] = -u[i];
 }
 
 // ---- per-iteration kernels ------------------------------------------------------------------------------------------------
@@ -295,7 +296,7 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
         HIPC(hipDeviceSynchronize());   // uploads above used the null stream; everything from here on is ordered on `st`
     }
     const LdlSymbolic& symbolic() const override { return S; }
-    int launches_per_solve() const override { const int L = (int)S.level_ptr.size() - 1; return 2 + std::max(L - 1, 0) + L + (S.Nt > 0 ? 3 : 0); }
+    int launches_per_solve() const override { const int L = (int)S.level_ptr.size() - 1; return 2 + std::max(L - 1, 0) + L + (S.Nt > 0 ? 3 + (tail_signed ? 1 : 0) : 0); }
     double bytes_per_solve() const override {
         const double s = sizeof(T);
         return 2.0 * (double)S.ci.size() * (s + 4) + (double)S.ldt * S.ldt * s + 8.0 * S.N * s;
@@ -329,7 +330,6 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
             if (tail_signed) cholesky_signed<T>(st, ldt, Mt.p, dinv.p, fail.p + 1, tsgn.p, tmp.p);
             else cholesky<T>(st, ldt, Mt.p, dinv.p, fail.p + 1);
             build_sweep_matrix<T>(st, ldt, nb, Mt.p, dinv.p, St.p, tmp.p);
-            if (tail_signed) hipLaunchKernelGGL((k_ldl_sign_rows<T>), dim3((ldt + 255) / 256, ldt), dim3(256), 0, st, ldt, tsgn.p, St.p);
         }
         int f[2] = {0, 0};
         HIPC(hipMemcpyAsync(f, fail.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -359,7 +359,8 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
         for (int l = 1; l < L; ++l) fwd(S.level_ptr[l], S.level_ptr[l + 1], lpr_fwd[l]);          // level 0: leaves, nothing to subtract
         if (Nt > 0) {
             fwd(Ns, N, lpr_tail);                                                                   // tb = b_t - L_ts y_s
-            gemv_rows<T>(st, St.p, ldt, tb.p, tu.p, nullptr, T(1), T(0), 0, ldt, 0, ldt, 1);        // J inv(Lt) tb
+            gemv_rows<T>(st, St.p, ldt, tb.p, tu.p, nullptr, T(1), T(0), 0, ldt, 0, ldt, 1);        // inv(Lt) tb
+            if (tail_signed) hipLaunchKernelGGL((k_ldl_mul_sign<T>), dim3((ldt + 255) / 256), dim3(256), 0, st, ldt, tsgn.p, tu.p);   // J .
             gemv_rows<T>(st, St.p, ldt, tu.p, tx.p, nullptr, T(1), T(0), 0, ldt, 0, ldt, 2);        // inv(Lt)' .
         }
         for (int l = L - 1; l >= 0; --l) bwd(S.level_ptr[l], S.level_ptr[l + 1], lpr_bwd[l]);

@@ -147,11 +147,14 @@ def test_ldl_isotonic_800_unit_test_script(gpu, c_oracle):
 def test_mode_auto_follows_the_reference_rule(gpu, c_oracle):
     """SolveQuadraticProgram.jl:143-151: direct when n + m <= 5000 and the density is <= 0.4, else iterative.  Both branches are
     reached through `linearSolverMode = modeAuto` and solve to the reference tolerance."""
-    P, q, A, l, u = GenerateRandomQP(ProblemClass.randomQp, 200, rng=make_rng(5, 1))          # sparse, 300 rows, density 0.25: direct -> L D L'
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.lassoOptimization, 10, rng=make_rng(5, 1))  # sparse, 2040 rows, density < 0.001: direct -> L D L'
     assert gpu.AutoLinearSolverMode(P, A) == gpu.LinearSolverMode.modeDirect
-    x, flag = gpu.SolveQuadraticProgram(P, q, A, l, u, numIterations=20000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True)
-    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True)
-    assert int(flag) == io["convFlag"] and np.abs(x - xo).max() <= ABS_DEV_THR
+    info = {}
+    x, flag = gpu.SolveQuadraticProgram(P, q, A, l, u, numIterations=20000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True, info=info)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+    assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["cgIterations"] == 0 and np.abs(x - xo).max() <= ABS_DEV_THR
+    Pr, qr, Ar, lr, ur = GenerateRandomQP(ProblemClass.randomQp, 200, rng=make_rng(5, 1))     # P = M'M is 99 % full: density 0.47 > 0.4 -> iterative
+    assert gpu.AutoLinearSolverMode(Pr, Ar) == gpu.LinearSolverMode.modeItertaive
     P, q, A, l, u = GenerateRandomQP(ProblemClass.randomQp, 4000, numConstraints=2000, densityFctr=0.003, rng=make_rng(5, 2))   # 6000 rows: iterative
     assert gpu.AutoLinearSolverMode(P, A) == gpu.LinearSolverMode.modeItertaive
     info = {}
