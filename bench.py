@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- ADMM iterations/sec of the device-resident loop on BASELINE.json's headline config
+"""bench.py -- ADMM iterations/sec of the device-resident loop on BASELINE.json's configs; the default is the headline one
 (dense n = 4096, m = 8192, fp64, one QP per GPU; ranks run independent replicas, no data-path collective).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU, RCCL for the timing gather)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one qps_solve() of --iters (default 500) ADMM iterations (ϵAbs = ϵRel = 0, adptΡ off, reference defaults otherwise) on a
-problem already resident in HBM with its factorisation cached (setup is reported separately).
-Rank 0 prints ONE JSON line.
+A "step" is one qps_solve() of --iters ADMM iterations (default 500; ϵAbs = ϵRel = 0 so exactly that many run) on a problem already
+resident in HBM with its factorisation cached (setup is reported separately).  Rank 0 prints ONE JSON line carrying
+`roofline` (dominant kernel, HIP events attached to its dispatches on the solver's stream, inside the timed region) and
+`cpu_baseline` (the oracle's C restatement on this box's host cores, bounded sample; rank 0 at N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -28,6 +31,8 @@ CONFIGS = {
     "c3": dict(n=50000, m=100000, dtype="f64", label="sparse P,A n=50k m=100k ~0.1% nnz fp64, CSR SpMV + matrix-free CG (configs[2])"),
     "c4": dict(n=1024, m=2048, dtype="f64", batch=256, label="batch of 256 dense n=1024 m=2048 QPs sharded across the ranks (configs[3])"),
 }
+SWEEP_VARIANTS = {0: None, 1: "blocked substitution (2n/nb-1 dependent phases per sweep)", 2: "explicit inverse, both sweeps fused into one pass over the triangle",
+                  3: "explicit inverse, two triangular GEMVs", 4: "single-launch small-problem loop"}
 
 
 def spawn_ranks_if_needed(args, argv):
@@ -60,13 +65,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=500, help="ADMM iterations per step")
+    ap.add_argument("--iters", type=int, default=0, help="ADMM iterations per step (default 500; 100 for c3 / c4; 2000 for c1)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--trsv-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-eps", action="store_true")
     ap.add_argument("--profile-level", type=int, default=1,
-                    help="1: HIP-event bracket the dominant kernel on every 50th iteration; 2: every launch of every kernel")
+                    help="1: HIP events on sampled dispatches of the loop kernels (well under 1 %% overhead); 2: every launch of every kernel")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="rank plumbing only (rendezvous, barrier, timing reduction) with a sleep in place of the solver: runs without a GPU")
     args = ap.parse_args()
@@ -88,24 +93,58 @@ def main():
         return launcher_selftest(args, info, backend, device, ndev, qd)
     import quadraticprogramsolver_amd as qps
     cfg = CONFIGS[args.config]
-    n, m = cfg["n"], cfg["m"]
-    s = 8 if cfg["dtype"] == "f64" else 4
-
+    if args.iters <= 0:
+        args.iters = {"c3": 100, "c4": 100, "c1": 2000}.get(args.config, 500)
     if torch.cuda.is_available():
         torch.cuda.set_device(device)      # torch.cuda.synchronize() below must act on this rank's GPU, not on GPU 0
-    if args.config in ("c3", "c4"):
-        return side_config(args, cfg, info, backend, device, qps, qd, np, torch)
-    # synthetic input: randomQp at density 1.0, seed 1234, one independent stream per rank (weak scaling)
+    sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
+    run = {"c2": run_dense, "c5": run_dense, "c1": run_dense, "c3": run_sparse, "c4": run_batch}[args.config]
+    out = run(args, cfg, info, device, qps, qd, np, sync)
+    if info.rank == 0:
+        out["config"]["dist_backend"] = backend
+        out["config"]["ranks"] = info.world_size
+        out["config"]["devices_visible"] = ndev
+        print(json.dumps(out), flush=True)
+    qd.shutdown(info)
+
+
+def base_line(args, cfg, info, value, tmax, scaling, metric="ADMM iterations/sec"):
+    return {"metric": metric, "value": round(value, 2), "unit": "iterations/s", "n_gpus": info.world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(tmax / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic", "config": {"workload": cfg["label"], "n": cfg["n"], "m": cfg["m"], "admm_iterations_per_step": args.iters}}
+
+
+def roofline_of(kernel_label, seconds, launches, algo_bytes_per_launch, traffic, traffic_src, extra=None):
+    dur = seconds / launches
+    ach = algo_bytes_per_launch / dur / 1e9
+    r = {"bound": "hbm", "kernel": kernel_label, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(dur * 1e6, 2), "algo_bytes_per_launch": algo_bytes_per_launch,
+         "launches_timed": launches, "timing": "HIP events attached to the sampled dispatches on the solver's stream, inside the timed region"}
+    if traffic:
+        r["traffic_over_algorithmic"] = round(traffic / algo_bytes_per_launch, 3)
+        r["traffic_GBs"] = round(traffic / dur / 1e9, 1)
+    if extra:
+        r.update(extra)
+    return r
+
+
+def kernel_list(ktimes):
+    return [{"name": k["name"], "avg_us": round(k["seconds"] / k["launches"] * 1e6, 2), "launches": k["launches"],
+             "GBs": round(k["algo_bytes"] / (k["seconds"] / k["launches"]) / 1e9, 1) if k["algo_bytes"] > 0 else None} for k in ktimes]
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# dense single-QP configs: c2 (headline), c5 (fp32 + refactor per check), c1 (plumbing shape, single-launch loop)
+# ----------------------------------------------------------------------------------------------------------------------------------
+def run_dense(args, cfg, info, device, qps, qd, np, sync):
+    n, m = cfg["n"], cfg["m"]
+    s = 8 if cfg["dtype"] == "f64" else 4
+    # synthetic input: randomQp at density 1.0, seed 1234, one independent stream per rank (weak scaling: replicas)
     P, q, A, l, u = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank)
     prob = qps.QuadraticProgram(P, q, A, l, u, dtype=cfg["dtype"], device=device)
     solve_kw = dict(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, trsvBlock=args.trsv_block, reuseFactor=True)
     if args.config == "c5":
         solve_kw.update(adptΡ=True, fctrΡ=1.0, numItrConv=50, ρ=0.1)   # ρ proposal applied (=> refactor) at every check
-
-    def sync():
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-
     setup_info = {}
     x = np.zeros(n)
     prob.solve(x, **dict(solve_kw, numIterations=min(args.iters, 25), reuseFactor=False), info=setup_info)   # builds + caches the factor
@@ -113,52 +152,51 @@ def main():
         x = np.zeros(n)
         prob.solve(x, **solve_kw)
     prob.set_profiling(args.profile_level)
-    iters_done = 0
-    loop_device_s = 0.0
+    iters_done, refactors, t_refactor, last = 0, 0, 0.0, {}
     qd.barrier(info); sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x = np.zeros(n); si = {}
         prob.solve(x, **solve_kw, info=si)
-        iters_done += si["iterations"]; loop_device_s += si["tLoop"]
+        iters_done += si["iterations"]; refactors += si["numRefactor"]; t_refactor += si["tRefactor"]; last = si
     sync(); qd.barrier(info)
     elapsed = time.perf_counter() - t0
     ktimes = prob.kernel_times()   # HIP-event times accumulated over the timed steps (reset by set_profiling)
     prob.set_profiling(0)
     value, tmax = qd.gather_timings(info, elapsed, iters_done)
-
     out = None
     if info.rank == 0:
+        out = base_line(args, cfg, info, value, tmax, "weak")
         b_iter = s * (m * n + n * n) + s * (6 * n + 10 * m)       # SURVEY §8d algorithmic bytes per ADMM iteration
-        # dominant kernel of the loop: the fused A-pass (sampled at level 1); fall back to the largest accumulated time
-        dom = next((k for k in ktimes if k["name"].startswith("apass(fused")), None) or (max(ktimes, key=lambda k: k["seconds"]) if ktimes else None)
-        roofline = None
-        if dom:
-            dur = dom["seconds"] / dom["launches"]
-            ach = dom["algo_bytes"] / dur / 1e9
-            traffic, traffic_src = pmc_traffic(dom["name"], cfg["dtype"])
-            roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "avg_launch_us": round(dur * 1e6, 2), "algo_bytes_per_launch": dom["algo_bytes"],
-                        "launches_timed": dom["launches"]}
+        small = next((k for k in ktimes if k["name"].startswith("admm_small")), None)
+        dom = next((k for k in ktimes if k["name"].startswith("apass(fused")), None)
+        if small:      # c1: the whole loop is one launch; its category carries bytes per ITERATION
+            out["roofline"] = roofline_of(small["name"], small["seconds"], small["launches"], b_iter * iters_done / small["launches"], None, None,
+                                          {"note": "latency-bound single-workgroup launch (one CU): the HBM roofline is quoted for completeness, the working set lives in registers / LDS"})
+        elif dom:
+            traffic, src = pmc_traffic(args.config, r"k_apass<.*false, 0>$")
+            out["roofline"] = roofline_of(dom["name"], dom["seconds"], dom["launches"], dom["algo_bytes"], traffic, src)
+        else:
+            out["roofline"] = None
         per_gpu = value / info.world_size
-        out = {
-            "metric": "ADMM iterations/sec", "value": round(value, 2), "unit": "iterations/s", "n_gpus": info.world_size,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tmax / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
-            "config": {"workload": cfg["label"], "n": n, "m": m, "admm_iterations_per_step": args.iters,
-                       "qps_per_gpu": 1, "parallelism": f"replicas x{info.world_size} (independent QPs, no collective)",
-                       "params": "eps=0, adptRho off, rho=1, sigma=1e-6, alpha=1.6, numItrConv=25 (SolveQuadraticProgram.jl:15-17)"
-                                 if args.config != "c5" else "fp32, adptRho on, fctrRho=1, numItrConv=50 (refactor at every check)",
-                       "dist_backend": backend},
-            "roofline": roofline,
-            "loop_roofline": {"algo_bytes_per_iteration": b_iter, "achieved_GBs": round(b_iter * per_gpu / 1e9, 1),
-                              "frac_of_8TBs": round(b_iter * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
-                              "frac_of_6.29TBs": round(b_iter * per_gpu / 1e9 / HBM_ACHIEVABLE_GBS, 4)},
-            "setup_ms": round(setup_info.get("tSetup", 0.0) * 1e3, 2),
-            "kernels": [{"name": k["name"], "avg_us": round(k["seconds"] / k["launches"] * 1e6, 2), "launches": k["launches"],
-                         "algo_GBs": round(k["algo_bytes"] / (k["seconds"] / k["launches"]) / 1e9, 1)} for k in ktimes],
-        }
+        out["config"].update({"qps_per_gpu": 1, "parallelism": f"replicas x{info.world_size} (independent QPs, no collective)",
+                              "trsv_block": last.get("trsvBlock"), "sweep_variant": SWEEP_VARIANTS.get(last.get("sweepVariant")),
+                              "params": ("eps=0, adptRho off, rho=1, sigma=1e-6, alpha=1.6, numItrConv=25 (SolveQuadraticProgram.jl:15-17)" if args.config != "c5"
+                                         else "fp32, eps=0, adptRho on, fctrRho=1, numItrConv=50, rho0=0.1: the proposal is applied (re-factorisation) at every check")})
+        out["loop_roofline"] = {"algo_bytes_per_iteration": b_iter, "achieved_GBs": round(b_iter * per_gpu / 1e9, 1),
+                                "frac_of_8TBs": round(b_iter * per_gpu / 1e9 / HBM_PEAK_GBS, 4), "frac_of_6.29TBs": round(b_iter * per_gpu / 1e9 / HBM_ACHIEVABLE_GBS, 4)}
+        out["setup_ms"] = round(setup_info.get("tSetup", 0.0) * 1e3, 2)
+        if refactors:
+            out["refactor"] = {"count": refactors, "ms_each": round(t_refactor / refactors * 1e3, 3), "share_of_loop_time": round(t_refactor / elapsed, 3)}
+        out["kernels"] = kernel_list(ktimes)
+        sw = next((k for k in ktimes if k["name"].startswith("sweeps(fused")), None)
+        if sw:   # the fused kernel reads the triangle once; SURVEY §8d's figure for the two sweeps it replaces is s*(n(n+1) + 4n)
+            dur = sw["seconds"] / sw["launches"]
+            t_sw, src_sw = pmc_traffic(args.config, r"k_sweep_fused<")
+            out["sweep_roofline"] = {"kernel": sw["name"], "avg_launch_us": round(dur * 1e6, 2), "kernel_bytes": sw["algo_bytes"],
+                                     "GBs": round(sw["algo_bytes"] / dur / 1e9, 1), "frac_of_8TBs": round(sw["algo_bytes"] / dur / 1e9 / HBM_PEAK_GBS, 4),
+                                     "two_sweep_algo_bytes": s * (n * (n + 1) + 4 * n), "two_sweep_algo_GBs": round(s * (n * (n + 1) + 4 * n) / dur / 1e9, 1),
+                                     "traffic": t_sw, "traffic_frac_of_8TBs": round(t_sw / dur / 1e9 / HBM_PEAK_GBS, 4) if t_sw else None, "traffic_source": src_sw}
         if not args.no_time_to_eps and args.config == "c2":
             # time-to-eps on the feasible variant (the plain m = 2n draw is primal infeasible: see generator docstring)
             Pf, qf, Af, lf, uf = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank, feasible=True)
@@ -171,12 +209,126 @@ def main():
                                       "ms_setup": round(ti["tSetup"] * 1e3, 2), "ms_loop": round(ti["tLoop"] * 1e3, 2),
                                       "problem": "randomQp density 1.0, bounds centred on A*x0 (feasible variant)"}
             del Pf, Af
-        if not args.no_cpu_baseline and info.world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(P, q, A, l, u, args.config)
+        out["cpu_baseline"] = cpu_baseline_dense(P, q, A, l, u, args.config) if (not args.no_cpu_baseline and info.world_size == 1) else None
     prob.close()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# c3: CSR / matrix-free CG, replicas
+# ----------------------------------------------------------------------------------------------------------------------------------
+def run_sparse(args, cfg, info, device, qps, qd, np, sync):
+    n, m = cfg["n"], cfg["m"]
+    P, q, A, l, u = qps.GenerateSparseBenchmarkQP(n, m, seed=1234 + info.rank)
+    solver = qps.QuadraticProgram(P, q, A, l, u, linsys="cg", dtype=cfg["dtype"], device=device)
+    cg = {"n": 0}
+
+    def run():
+        x = np.zeros(n); si = {}
+        solver.solve(x, numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, info=si)
+        cg["n"] += si["cgIterations"]
+    run()
+    for _ in range(args.warmup):
+        run()
+    cg["n"] = 0
+    solver.set_profiling(args.profile_level)
+    qd.barrier(info); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync(); qd.barrier(info)
+    elapsed = time.perf_counter() - t0
+    ktimes = solver.kernel_times()
+    solver.set_profiling(0)
+    value, tmax = qd.gather_timings(info, elapsed, args.iters * args.steps)
+    out = None
     if info.rank == 0:
-        print(json.dumps(out), flush=True)
-    qd.shutdown(info)
+        out = base_line(args, cfg, info, value, tmax, "weak")
+        pnnz, annz = P.nnz, A.nnz
+        spmv = lambda nnz, rows, cols: nnz * 12 + rows * 4 + 8 * (rows + cols)
+        cg_bytes = spmv(annz, m, n) + spmv(annz, n, m) + spmv(pnnz, n, n) + 8 * (10 * n + 2 * m)
+        cg_per_admm = cg["n"] / (args.iters * args.steps)
+        out["config"].update({"parallelism": f"replicas x{info.world_size}", "nnz_P": int(pnnz), "nnz_A": int(annz),
+                              "params": "eps=0, rho=1, sigma=1e-6, epsPcg=1e-6, numItrPcg=1000 (LinearSystemSolvers.jl:164), no preconditioner"})
+        blk = [k for k in ktimes if k["name"].startswith("spmv_blk(")]
+        if blk:   # both column-blocked products of a CG iteration run the same kernel: they are timed in pairs and reported together
+            secs, launches = sum(k["seconds"] for k in blk), sum(k["launches"] for k in blk)
+            bytes_avg = sum(k["algo_bytes"] * k["launches"] for k in blk) / launches
+            traffic, src = pmc_traffic("c3", r"k_spmv_blk<")
+            out["roofline"] = roofline_of("k_spmv_blk ([P;A] u and A' v of a CG iteration, x block in LDS)", secs, launches, bytes_avg, traffic, src,
+                                          {"note": "the ~155 MB working set is Infinity-Cache resident (256 MiB): fractions are against the HBM peak all the same"})
+        else:
+            out["roofline"] = None
+        out["cg_iterations_per_s"] = round(cg["n"] / elapsed, 1)
+        out["cg_iterations_per_admm_iteration"] = round(cg_per_admm, 2)
+        out["loop_roofline"] = {"algo_bytes_per_cg_iteration": cg_bytes, "achieved_GBs": round(cg_bytes * cg["n"] / elapsed / 1e9, 1),
+                                "frac_of_8TBs": round(cg_bytes * cg["n"] / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+        out["kernels"] = kernel_list(ktimes)
+        out["cpu_baseline"] = cpu_baseline_sparse(P, q, A, l, u) if (not args.no_cpu_baseline and info.world_size == 1) else None
+    solver.close()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# c4: the 256-QP batch cut into contiguous slabs, one per rank, no collective
+# ----------------------------------------------------------------------------------------------------------------------------------
+def run_batch(args, cfg, info, device, qps, qd, np, sync):
+    n, m = cfg["n"], cfg["m"]
+    begin, end = qd.shard_range(cfg["batch"], info.rank, info.world_size)      # QP b -> rank b // ceil(256 / world)
+    probs = [qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b) for b in range(begin, end)]
+    solver = qps.QuadraticProgramBatch(probs, dtype=cfg["dtype"], device=device)
+    first = probs[0]
+    del probs
+    run = lambda: solver.solve(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, reuseFactor=True)
+    run()
+    for _ in range(args.warmup):
+        run()
+    set_batch_profiling(solver, args.profile_level)
+    qd.barrier(info); sync()
+    t0 = time.perf_counter()
+    infos = None
+    for _ in range(args.steps):
+        _, _, infos = run()
+    sync(); qd.barrier(info)
+    elapsed = time.perf_counter() - t0
+    ktimes = batch_kernel_times(solver)
+    set_batch_profiling(solver, 0)
+    units = (end - begin) * args.iters * args.steps
+    value, tmax = qd.gather_timings(info, elapsed, units)
+    out = None
+    if info.rank == 0:
+        out = base_line(args, cfg, info, value, tmax, "strong", "ADMM iterations/sec (QP-iterations, summed over the batch)")
+        b_iter = 8 * (m * n + n * n) + 8 * (6 * n + 10 * m)
+        per_gpu = value / info.world_size
+        out["config"].update({"batch": cfg["batch"], "qps_on_rank0": end - begin, "parallelism": f"256 QPs in {info.world_size} contiguous slab(s), no collective",
+                              "trsv_block": infos[0].get("trsvBlock"), "sweep_variant": SWEEP_VARIANTS.get(infos[0].get("sweepVariant")),
+                              "params": "eps=0, adptRho off, rho=1, sigma=1e-6, alpha=1.6, numItrConv=25"})
+        dom = next((k for k in ktimes if k["name"].startswith("apass(fused")), None)
+        if dom:
+            traffic, src = pmc_traffic("c4", r"k_apass<.*false, 0>$")
+            out["roofline"] = roofline_of(dom["name"], dom["seconds"], dom["launches"], dom["algo_bytes"], traffic, src)
+        else:
+            out["roofline"] = None
+        out["loop_roofline"] = {"algo_bytes_per_qp_iteration": b_iter, "achieved_GBs": round(b_iter * per_gpu / 1e9, 1),
+                                "frac_of_8TBs": round(b_iter * per_gpu / 1e9 / HBM_PEAK_GBS, 4), "frac_of_6.29TBs": round(b_iter * per_gpu / 1e9 / HBM_ACHIEVABLE_GBS, 4)}
+        out["kernels"] = kernel_list(ktimes)
+        out["cpu_baseline"] = cpu_baseline_batch(first, cfg["batch"]) if (not args.no_cpu_baseline and info.world_size == 1) else None
+    solver.close()
+    return out
+
+
+def set_batch_profiling(solver, level):
+    from quadraticprogramsolver_amd import _lib
+    _lib.check(_lib.lib().qps_set_profiling(solver._h, int(level)), solver._h)
+
+
+def batch_kernel_times(solver):
+    import ctypes as C
+    from quadraticprogramsolver_amd import _lib
+    buf = (_lib.QpsKernelTime * 32)()
+    cnt = C.c_int32(0)
+    _lib.check(_lib.lib().qps_kernel_times(solver._h, buf, 32, C.byref(cnt)), solver._h)
+    return [dict(name=buf[i].name.decode(), seconds=buf[i].seconds, launches=buf[i].launches, algo_bytes=buf[i].algo_bytes) for i in range(cnt.value)]
 
 
 def launcher_selftest(args, info, backend, device, ndev, qd):
@@ -197,92 +349,73 @@ def launcher_selftest(args, info, backend, device, ndev, qd):
     qd.shutdown(info)
 
 
-def side_config(args, cfg, info, backend, device, qps, qd, np, torch):
-    """Configs that are not the headline line: c3 (CSR/CG, replicas) and c4 (the 256-QP batch cut into contiguous slabs,
-    one per rank, no collective).  Same timing contract: W warm-up steps, K timed steps between barrier + synchronize."""
-    n, m = cfg["n"], cfg["m"]
-    sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
-    if args.iters == 500:
-        args.iters = 100          # side configs: shorter steps
-    if args.config == "c4":
-        begin, end = qd.shard_range(cfg["batch"], info.rank, info.world_size)      # QP b -> rank b // ceil(256 / world)
-        probs = [qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b) for b in range(begin, end)]
-        solver = qps.QuadraticProgramBatch(probs, dtype=cfg["dtype"], device=device)
-        run = lambda: solver.solve(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, reuseFactor=True)
-        units_per_step = (end - begin) * args.iters
-        algo_bytes_per_unit = 8 * (m * n + n * n) + 8 * (6 * n + 10 * m)
-    else:
-        P, q, A, l, u = qps.GenerateSparseBenchmarkQP(n, m, seed=1234 + info.rank)
-        solver = qps.QuadraticProgram(P, q, A, l, u, linsys="cg", dtype=cfg["dtype"], device=device)
-        cg = {"n": 0}
-        def run():
-            x = np.zeros(n); si = {}
-            solver.solve(x, numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, info=si)
-            cg["n"] += si["cgIterations"]
-        units_per_step = args.iters
-        algo_bytes_per_unit = None
-    run()
-    for _ in range(args.warmup):
-        run()
-    if args.config == "c3":
-        cg["n"] = 0
-    qd.barrier(info); sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    sync(); qd.barrier(info)
-    elapsed = time.perf_counter() - t0
-    value, tmax = qd.gather_timings(info, elapsed, units_per_step * args.steps)
-    if info.rank == 0:
-        out = {"metric": "ADMM iterations/sec" + (" (QP-iterations, summed over the batch)" if args.config == "c4" else ""),
-               "value": round(value, 2), "unit": "iterations/s", "n_gpus": info.world_size, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(tmax / args.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
-               "config": {"workload": cfg["label"], "n": n, "m": m, "admm_iterations_per_step": args.iters, "dist_backend": backend,
-                          "parallelism": (f"256 QPs in {info.world_size} contiguous slab(s), no collective" if args.config == "c4"
-                                          else f"replicas x{info.world_size}")},
-               "roofline": None, "cpu_baseline": None}
-        if algo_bytes_per_unit:
-            per_gpu = value / info.world_size
-            out["loop_roofline"] = {"algo_bytes_per_iteration": algo_bytes_per_unit, "achieved_GBs": round(algo_bytes_per_unit * per_gpu / 1e9, 1),
-                                    "frac_of_8TBs": round(algo_bytes_per_unit * per_gpu / 1e9 / HBM_PEAK_GBS, 4)}
-        if args.config == "c3":
-            out["cg_iterations_per_s"] = round(cg["n"] / elapsed, 1)
-            out["cg_iterations_per_admm_iteration"] = round(cg["n"] / (units_per_step * args.steps), 2)
-        print(json.dumps(out), flush=True)
-    solver.close()
-    qd.shutdown(info)
-
-
-def pmc_traffic(kernel_label, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and, in a
-    separate pass, --pmc WRITE_SIZE on this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters
-    cannot be read from inside the timed process, so the figure comes from profiles/ (or null when absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not (os.path.exists(path) and kernel_label.startswith("apass(fused") and dtype == "f64"):
+def pmc_traffic(config, kernel_regex):
+    """HBM bytes per launch of a kernel from the committed PMC passes of this config (rocprofv3 --pmc FETCH_SIZE and, in a separate
+    pass, --pmc WRITE_SIZE on this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; tests/tools/pmc_summary.py).  PMC
+    counters cannot be read from inside the timed process, so the figure comes from the newest profiles/rNN_*pmc_traffic_<config>.json."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*pmc_traffic_{config}.json")))
+    if not files and config == "c2":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    if not files:
         return None, None
     try:
-        d = json.load(open(path))
+        d = json.load(open(files[-1]))
+        best = None
         for name, v in d.items():
-            if name.startswith("k_apass<double") and (name.endswith("false>") or name.endswith("false, 0>")):   # the plain ADMM variant
-                return v["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+            if re.search(kernel_regex, name) and (best is None or v.get("launches", v.get("launches_sampled", 0)) > best[1].get("launches", best[1].get("launches_sampled", 0))):
+                best = (name, v)
+        if best:
+            return best[1]["hbm_bytes_per_launch"], f"profiles/{os.path.basename(files[-1])}: {best[0]} (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
     except Exception:
         pass
     return None, None
 
 
-def cpu_baseline(P, q, A, l, u, config):
-    """The oracle's C restatement (kind "port": the Julia reference cannot run in this pipeline) timed on this box's
-    host cores on a bounded sample of the same workload: the full setup + 50 iterations on all cores, then 10
-    iterations of the loop on one core (the reference loop and its LDL solves are single-threaded)."""
+# ----------------------------------------------------------------------------------------------------------------------------------
+# CPU baselines: the oracle's C restatement (kind "port": the Julia reference cannot run in this pipeline) on a bounded sample
+# ----------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_dense(P, q, A, l, u, config):
+    """Same problem as the GPU run: full setup + 50 iterations on all cores (OpenMP: GEMVs over rows, blocked triangular solves with
+    shared panels), then 10 iterations on one core (the reference loop and its LDL' solves are single-threaded).  c5 runs the same
+    refactor-per-check schedule (fp64: the oracle has no fp32 path)."""
     from oracle import c_oracle as co
     cores = co.available_cores()   # min(affinity mask, cgroup CPU quota)
-    x, i_all = co.solve(P, q, A, l, u, numIterations=50, epsAbs=0.0, epsRel=0.0, numThreads=cores)
-    x, i_one = co.solve(P, q, A, l, u, numIterations=10, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1)
-    return {"value": round(50 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": "same problem as the GPU run: full setup + 50 ADMM iterations on all cores (OpenMP over rows); "
-                      "single-thread loop rate from 10 more iterations",
-            "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(10 / i_one["tLoop"], 3),
+    kw = dict(epsAbs=0.0, epsRel=0.0)
+    if config == "c5":
+        kw.update(adptRho=True, fctrRho=1.0, numItrConv=50, rho=0.1)
+    its = 100 if config != "c1" else 20000
+    x, i_all = co.solve(P, q, A, l, u, numIterations=its, numThreads=cores, **kw)
+    x, i_one = co.solve(P, q, A, l, u, numIterations=max(its // 5, 10), numThreads=cores, loopThreads=1, **kw)
+    sample = (f"same problem as the GPU run: full setup + {its} ADMM iterations on all cores (OpenMP; blocked triangular solves); single-thread loop rate from "
+              f"{max(its // 5, 10)} more iterations" + ("; refactor at every check (fp64 oracle: no fp32 CPU path)" if config == "c5" else ""))
+    return {"value": round(its / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample,
+            "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(max(its // 5, 10) / i_one["tLoop"], 3),
+            "refactorisations_in_sample": i_all["numRefactor"],
+            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
+
+
+def cpu_baseline_sparse(P, q, A, l, u):
+    """c3: the oracle's CSC + matrix-free CG plugin (LinearSystemSolvers.jl:145-186) on the same problem, 10 ADMM iterations."""
+    from oracle import c_oracle as co
+    cores = co.available_cores()
+    x, i_all = co.solve(P, q, A, l, u, numIterations=10, epsAbs=0.0, epsRel=0.0, numThreads=cores, linsys=co.KIND_CG_MATFREE)
+    x, i_one = co.solve(P, q, A, l, u, numIterations=4, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1, linsys=co.KIND_CG_MATFREE)
+    return {"value": round(10 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": "same problem as the GPU run: 10 ADMM iterations (matrix-free CG, epsPcg 1e-6) on all cores (OpenMP over the CSC columns); single-thread rate from 4 more",
+            "cg_iterations_per_s": round(i_all["cgIterations"] / i_all["tLoop"], 1), "single_thread_iterations_per_s": round(4 / i_one["tLoop"], 3),
+            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
+
+
+def cpu_baseline_batch(first, batch):
+    """c4: a CPU runs the QPs one after the other, so its QP-iterations/s is the rate of one QP (n = 1024): 200 iterations of QP 0."""
+    from oracle import c_oracle as co
+    cores = co.available_cores()
+    P, q, A, l, u = first
+    x, i_all = co.solve(P, q, A, l, u, numIterations=200, epsAbs=0.0, epsRel=0.0, numThreads=cores)
+    x, i_one = co.solve(P, q, A, l, u, numIterations=200, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1)
+    return {"value": round(200 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"QP 0 of the batch: full setup + 200 ADMM iterations on all cores; the {batch} QPs would run back to back at this QP-iteration rate",
+            "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(200 / i_one["tLoop"], 3),
             "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
 
 

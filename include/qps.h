@@ -112,6 +112,10 @@ typedef struct {
                                 1 the last MINRES call did not converge (x kept) */
     int32_t polishIterations;/* total MINRES iterations of the polishing step */
     double tPolish;          /* seconds spent polishing (not part of tLoop) */
+    int32_t trsvBlock;       /* dense handles: size of the inverted diagonal blocks the triangular sweeps ran with (0: not a dense Cholesky run) */
+    int32_t sweepVariant;    /* dense handles: 1 = blocked substitution over the sweep matrix (2 n / trsvBlock - 1 dependent phases per sweep),
+                                2 = explicit inverse, both sweeps fused into one pass over the triangle (trsvBlock >= n),
+                                3 = explicit inverse, two triangular GEMVs, 4 = single-launch small-problem loop; 0 otherwise */
 } qps_info;
 
 /* Fill *p with the reference defaults (SolveQuadraticProgram.jl:15-17). */

@@ -235,20 +235,48 @@ static int64_t dense_cholesky(int64_t n, double *M) {
     }
     return 0;
 }
-/* Solve L L' x = b in place (two triangular sweeps).  ProxQP.jl:224 ldiv!(vX, sC, vR). */
+/* Solve L L' x = b in place (two triangular sweeps).  ProxQP.jl:224 ldiv!(vX, sC, vR).
+ * Blocked so that the all-cores CPU baseline is not one core's TRSV: 256-wide diagonal blocks are substituted serially
+ * (n * 256 / 2 multiply-adds per sweep), the panels below / beside them -- all but 1/16 of the triangle at n = 4096 -- are
+ * GEMV-shaped and shared by the OpenMP threads over contiguous column segments. */
 static void dense_chol_solve(int64_t n, const double *L, double *b) {
-    /* forward: column-oriented (axpy) for contiguous access */
-    for (int64_t j = 0; j < n; ++j) {
-        double xj = b[j] / L[j + j * n];
-        b[j] = xj;
-        const double *col = L + j * n;
-        for (int64_t i = j + 1; i < n; ++i) b[i] -= col[i] * xj;
+    const int64_t NB = 256;
+    /* forward: L y = b */
+    for (int64_t j0 = 0; j0 < n; j0 += NB) {
+        int64_t j1 = j0 + NB < n ? j0 + NB : n;
+        for (int64_t j = j0; j < j1; ++j) {                      /* diagonal block, column-oriented (axpy) */
+            double xj = b[j] / L[j + j * n];
+            b[j] = xj;
+            const double *col = L + j * n;
+            for (int64_t i = j + 1; i < j1; ++i) b[i] -= col[i] * xj;
+        }
+        if (j1 < n) {                                            /* b[j1:] -= L[j1:, j0:j1] * y[j0:j1], rows shared by the threads */
+#pragma omp parallel for schedule(static) if ((n - j1) * (j1 - j0) > OQ_PAR_MIN / 4)
+            for (int64_t i0 = j1; i0 < n; i0 += 512) {
+                int64_t i1 = i0 + 512 < n ? i0 + 512 : n;
+                for (int64_t j = j0; j < j1; ++j) {
+                    const double *col = L + j * n; double xj = b[j];
+                    for (int64_t i = i0; i < i1; ++i) b[i] -= col[i] * xj;
+                }
+            }
+        }
     }
-    /* backward: L' x = y, dot-product oriented over column j of L */
-    for (int64_t j = n - 1; j >= 0; --j) {
-        const double *col = L + j * n; double s = b[j];
-        for (int64_t i = j + 1; i < n; ++i) s -= col[i] * b[i];
-        b[j] = s / L[j + j * n];
+    /* backward: L' x = y, dot products over the columns of L */
+    for (int64_t j1 = n; j1 > 0; j1 -= NB) {
+        int64_t j0 = j1 - NB > 0 ? j1 - NB : 0;
+        if (j1 < n) {                                            /* b[j] -= L[j1:, j]' x[j1:] for the columns of this block */
+#pragma omp parallel for schedule(static) if ((n - j1) * (j1 - j0) > OQ_PAR_MIN / 4)
+            for (int64_t j = j0; j < j1; ++j) {
+                const double *col = L + j * n; double s = 0.0;
+                for (int64_t i = j1; i < n; ++i) s += col[i] * b[i];
+                b[j] -= s;
+            }
+        }
+        for (int64_t j = j1 - 1; j >= j0; --j) {                 /* diagonal block */
+            const double *col = L + j * n; double s = b[j];
+            for (int64_t i = j + 1; i < j1; ++i) s -= col[i] * b[i];
+            b[j] = s / L[j + j * n];
+        }
     }
 }
 /* Dense LDL' without pivoting of a symmetric quasi-definite matrix K (N x N, column-major, lower triangle):

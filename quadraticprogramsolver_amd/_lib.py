@@ -58,7 +58,8 @@ class QpsInfo(C.Structure):
     _fields_ = [("convFlag", C.c_int32), ("iterations", C.c_int32), ("numRefactor", C.c_int32),
                 ("cgIterations", C.c_int32), ("rhoFinal", C.c_double), ("rhoProposed", C.c_double),
                 ("resPrim", C.c_double), ("resDual", C.c_double), ("tSetup", C.c_double), ("tLoop", C.c_double),
-                ("tRefactor", C.c_double), ("polishFlag", C.c_int32), ("polishIterations", C.c_int32), ("tPolish", C.c_double)]
+                ("tRefactor", C.c_double), ("polishFlag", C.c_int32), ("polishIterations", C.c_int32), ("tPolish", C.c_double),
+                ("trsvBlock", C.c_int32), ("sweepVariant", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

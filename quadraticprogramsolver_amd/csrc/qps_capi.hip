@@ -106,7 +106,7 @@ template <typename T> struct DenseSolver : SolverBase {
     }
     int prof_iter = 0;   // iteration index seen by the level-1 sampler (one bracketed launch per kernel kind per 50 iterations)
     int sample_lvl(int slot) const { return (prof.level == 1 && prof_iter % 50 == slot) ? 1 : 2; }
-    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk, cat_sweep, cat_xsum;
+    int cat_atw, cat_colsum, cat_fwd, cat_bwd, cat_ax, cat_upd, cat_chk, cat_pass, cat_passchk, cat_sweep, cat_xsum, cat_small;
 
     DenseSolver(int dev, int64_t n_, int64_t m_, int dt) {
         device = dev; n = n_; m = m_; dtype = dt;
@@ -156,10 +156,12 @@ template <typename T> struct DenseSolver : SolverBase {
         // fused pass: A once + x~, x, z, y, l, u in, x, z, y out (s*m*n + vector traffic)
         cat_pass = prof.category("apass(fused A-pass)", s * ((double)m * n + 3.0 * n + 6.0 * m));
         cat_passchk = prof.category("apass(check variant)", s * ((double)m * n + 4.0 * n + 6.0 * m));
-        // fused forward+backward sweep: algorithmic bytes of BOTH sweeps (SURVEY §8d counts n(n+1)/2 per sweep); the kernel
-        // actually reads the triangle once
-        cat_sweep = prof.category("sweeps(fused fwd+bwd)", s * ((double)n * (n + 1) + 4.0 * n));
+        // fused forward+backward sweep: the bytes this kernel has to move -- the triangle ONCE (n(n+1)/2) plus its slabs; SURVEY §8d's
+        // figure for the two separate sweeps it replaces is twice the triangle (bench.py reports that one as `two_sweep_algo_GBs`)
+        cat_sweep = prof.category("sweeps(fused fwd+bwd, triangle read once)", s * ((double)n * (n + 1) / 2 + 2.0 * n + (double)sweep_fused_slabs<T>(NP) * n));
         cat_xsum = prof.category("colsum(x~ slabs)", s * ((double)sweep_fused_slabs<T>(NP) * n + n));
+        // single-launch small-problem loop: bytes PER ITERATION (one launch runs many; bench.py multiplies by the iterations it timed)
+        cat_small = prof.category("admm_small(whole loop in one launch; bytes per iteration)", s * ((double)m * n + (double)n * n) + s * (6.0 * n + 10.0 * m));
     }
     ~DenseSolver() override {
         (void)hipSetDevice(device);
@@ -229,6 +231,12 @@ template <typename T> struct DenseSolver : SolverBase {
         factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb;
     }
 
+    int sweep_variant() const {
+        const int nblk = (NP + nb - 1) / nb;
+        static const int sweep_mode = getenv("QPS_SWEEP_MODE") ? atoi(getenv("QPS_SWEEP_MODE")) : 2;
+        if (nblk == 1) return (sweep_mode == 2 && sweep_fused_supported<T>(NP)) ? 2 : 3;
+        return 1;
+    }
     // x~ = (L L')^{-1} tt via the blocked sweeps over S (tt is consumed)
     void sweeps() {
         const int nblk = (NP + nb - 1) / nb;
@@ -299,10 +307,14 @@ template <typename T> struct DenseSolver : SolverBase {
             transpose_small<T>(st, A, NP, MP, At);
             int it = 0;
             while (it < p.numIterations) {
-                admm_small<T>(st, (int)n, (int)m, NP, MP, it, p.numIterations, p.numItrConv, p.adptRho, rho, rhorho, sigma, alpha, p.epsAbs,
-                              p.epsRel, epsAdmm, p.fctrRho, A, At, P, S, q, l, u, x, xp, z, y, small_out);
+                {
+                    ProfScope ps(prof, cat_small, 1);   // events around the one launch (a ~3 us launch gap against a kernel of hundreds of us)
+                    admm_small<T>(st, (int)n, (int)m, NP, MP, it, p.numIterations, p.numItrConv, p.adptRho, rho, rhorho, sigma, alpha, p.epsAbs,
+                                  p.epsRel, epsAdmm, p.fctrRho, A, At, P, S, q, l, u, x, xp, z, y, small_out);
+                }
                 HIPC(hipMemcpyAsync(small_out_host, small_out, admm_small_out_bytes(), hipMemcpyDeviceToHost, st));
                 HIPC(hipStreamSynchronize(st));
+                prof.harvest();
                 int last = 0, flag = 1, need = 0; double r8[8];
                 admm_small_read(small_out_host, &last, &flag, &need, r8);
                 it = last; convFlag = flag; rhorho = r8[4];
@@ -325,6 +337,7 @@ template <typename T> struct DenseSolver : SolverBase {
                 info->rhoFinal = rho; info->rhoProposed = rhorho; info->resPrim = resP; info->resDual = resD;
                 info->tSetup = t1 - t0; info->tLoop = t2s - t1; info->tRefactor = tref;
                 info->polishFlag = prs.flag; info->polishIterations = prs.minresIterations; info->tPolish = prs.seconds;
+                info->trsvBlock = nb; info->sweepVariant = 4;
             }
             return;
         }
@@ -418,6 +431,7 @@ template <typename T> struct DenseSolver : SolverBase {
             info->numRefactor = nref; info->cgIterations = 0; info->rhoFinal = rho; info->rhoProposed = rhorho;
             info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = tref;
             info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
+            info->trsvBlock = nb; info->sweepVariant = sweep_variant();
         }
     }
     void polish(double* xh, const double* yh, const qps_params& p, qps_polish_report* rep) override {
@@ -459,7 +473,7 @@ template <typename T> struct DenseSolver : SolverBase {
 // ran its own SolveQuadraticProgram! (the tests compare every QP of a batch with its own stand-alone run).
 // =================================================================================================================
 struct BatchSolverBase {
-    int device = 0; int64_t n = 0, m = 0; int count = 0; std::string err;
+    int device = 0; int64_t n = 0, m = 0; int count = 0; std::string err; Profiler prof;
     virtual ~BatchSolverBase() {}
     virtual void solve_batch(double* x, const qps_params& p, qps_info* infos) = 0;
 };
@@ -476,13 +490,20 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
     int* h_int = nullptr; double* h_dbl = nullptr;   // pinned staging for the small per-QP arrays
     bool have_AA = false; double fac_sigma = -1; int fac_nb = -1; std::vector<double> fac_rho;   // per-QP factor cache
     char* sb_args = nullptr; void* sb_host = nullptr;                                              // small-batch path: argument / report slots
+    int cat_pass = 0, cat_sweep = 0;
 
     BatchedDenseSolver(int dev, int cnt, int64_t n_, int64_t m_) {
         device = dev; n = n_; m = m_; count = cnt;
         HIPC(hipSetDevice(device));
         HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        prof.st = st;
         NP = roundup(n, 64); MP = roundup(m, 64);
         slabs = apass_plan<T>(NP, MP, &rpw, count);
+        {   // algorithmic bytes per launch of the batched kernels: `count` times the single-QP figures
+            const double s = sizeof(T), c = cnt;
+            cat_pass = prof.category("apass(fused A-pass, batched)", c * s * ((double)m * n + 3.0 * n + 6.0 * m));
+            cat_sweep = prof.category("sweeps(fused fwd+bwd, batched, triangle read once)", c * s * ((double)n * (n + 1) / 2 + 2.0 * n));
+        }
         part_tiles = gemv_cols_tiles(MP);
         const int64_t nn = (int64_t)NP * NP, c = count;
         A = dalloc<T>(c * MP * NP); P = dalloc<T>(c * nn); PI = dalloc<T>(c * nn); AA = dalloc<T>(c * nn); M = dalloc<T>(c * nn);
@@ -506,6 +527,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
     ~BatchedDenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
+        prof.release_events();
         void* ptrs[] = {A, P, q, l, u, PI, AA, M, S, tmp, dinv, x, xp, xres, z, y, xx, tt, yv, part, part2, part_tmp, sw_part, Px, Aty, fail, d_active,
                         d_rho, d_rhorho, scratch, res_dev, stage};
         for (void* p_ : ptrs) if (p_) (void)hipFree(p_);
@@ -679,7 +701,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             colsum<T>(st, part, NP, rhs_slabs, x, (T)sigma, q, T(-1), tt, NP, bsC);                  // LinearSystemSolvers.jl:136
             if (nblk == 1 && sweep_fused_supported<T>(NP)) {                                       // both sweeps in one pass
                 BatchStride bsW = bsS; bsW.vout = (int64_t)sw_slabs * NP;
-                sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP, bsW);
+                { ProfLaunchScope ps(prof, cat_sweep, (prof.level == 1 && ii % 50 == 13) ? 1 : 2); sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP, bsW); }
                 BatchStride bsX = bsS; bsX.mat = (int64_t)sw_slabs * NP;
                 colsum<T>(st, sw_part, NP, sw_slabs, nullptr, T(0), nullptr, T(0), xx, NP, bsX);
             } else
@@ -695,7 +717,10 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 if (r0 > 0) gemv_rows<T>(st, S, NP, xx, yv, yv, T(-1), T(1), 0, r0, r0, r1, 0, bsS);
             }
             if (check) HIPC(hipMemsetAsync(scratch, 0, 16 * sizeof(unsigned long long) * count, st));
-            apass<T>(st, check, A, NP, NP, MP, xx, x, xp, z, y, l, u, (T)alpha, T(1), part, part2, NP, scratch, pb);   // :56-61 + next rhs
+            {
+                ProfLaunchScope ps(prof, cat_pass, (prof.level == 1 && !check && ii % 50 == 38) ? 1 : (check ? 3 : 2));   // level 1: one plain launch in 50
+                apass<T>(st, check, A, NP, NP, MP, xx, x, xp, z, y, l, u, (T)alpha, T(1), part, part2, NP, scratch, pb);   // :56-61 + next rhs
+            }
             std::swap(x, xp);
             rhs_slabs = slabs;
             if (check) {                                                                            // :63-69
@@ -706,6 +731,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 check_convergence<T>(st, (int)n, (int)m, (const T*)nullptr, Px, Aty, q, x, xp, z, z, scratch, res_dev, cs, 1, bsK, d_rho, d_rhorho);
                 HIPC(hipMemcpyAsync(res_host, res_dev, 8 * sizeof(double) * count, hipMemcpyDeviceToHost, st));
                 HIPC(hipStreamSynchronize(st));
+                prof.harvest();
                 bool any_done = false;
                 for (int b = 0; b < count; ++b) {
                     if (!active[b]) continue;
@@ -723,6 +749,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         for (int b = 0; b < count; ++b)
             if (active[b]) HIPC(hipMemcpyAsync(xres + (int64_t)b * NP, x + (int64_t)b * NP, sizeof(T) * NP, hipMemcpyDeviceToDevice, st));
         HIPC(hipStreamSynchronize(st));
+        prof.harvest();
         const double t2 = now_s();
         std::vector<PolishReport> pol(count);
         if (p.polish)                                                                               // SolveQuadraticProgram.m:289-325, one QP after the other
@@ -739,6 +766,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 in.rhoFinal = rho[b]; in.rhoProposed = rhorho[b]; in.resPrim = resP[b]; in.resDual = resD[b];
                 in.tSetup = t1 - t0; in.tLoop = t2 - t1; in.tRefactor = tref[b];   // wall time of the whole batch
                 in.polishFlag = pol[b].flag; in.polishIterations = pol[b].minresIterations; in.tPolish = pol[b].seconds;
+                in.trsvBlock = nb; in.sweepVariant = (nblk == 1 && sweep_fused_supported<T>(NP)) ? 2 : (nblk == 1 ? 3 : 1);
             }
         }
     }
@@ -1065,6 +1093,7 @@ QPS_API int32_t qps_set_profiling(qps_handle hh, int32_t on) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!h) return QPS_ERR_BAD_ARGUMENT;
     if (h->impl) { h->impl->prof.level = on; h->impl->prof.reset(); }
+    if (h->fused_batch) { h->fused_batch->prof.level = on; h->fused_batch->prof.reset(); }
     for (auto* s : h->batch) { s->prof.level = on; s->prof.reset(); }
     return QPS_OK;
 }
@@ -1073,14 +1102,15 @@ QPS_API int32_t qps_kernel_times(qps_handle hh, qps_kernel_time* out, int32_t ca
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!h || !count) return QPS_ERR_BAD_ARGUMENT;
     SolverBase* s = h->impl ? h->impl : (h->batch.empty() ? nullptr : h->batch[0]);
-    if (!s) return QPS_ERR_BAD_ARGUMENT;
+    Profiler* pf = s ? &s->prof : (h->fused_batch ? &h->fused_batch->prof : nullptr);
+    if (!pf) return QPS_ERR_BAD_ARGUMENT;
     int k = 0;
-    for (size_t i = 0; i < s->prof.names.size() && k < cap; ++i) {
-        if (s->prof.stats[i].launches == 0) continue;
+    for (size_t i = 0; i < pf->names.size() && k < cap; ++i) {
+        if (pf->stats[i].launches == 0) continue;
         if (out) {
             memset(&out[k], 0, sizeof(out[k]));
-            strncpy(out[k].name, s->prof.names[i].c_str(), sizeof(out[k].name) - 1);
-            out[k].seconds = s->prof.stats[i].seconds; out[k].launches = s->prof.stats[i].launches; out[k].algo_bytes = s->prof.stats[i].algo_bytes;
+            strncpy(out[k].name, pf->names[i].c_str(), sizeof(out[k].name) - 1);
+            out[k].seconds = pf->stats[i].seconds; out[k].launches = pf->stats[i].launches; out[k].algo_bytes = pf->stats[i].algo_bytes;
         }
         ++k;
     }

@@ -35,7 +35,7 @@ def test_default_params_are_the_reference_defaults(qps):
     assert (p.fctrRho, p.numItrConv, p.numItrPolish, p.epsMinres, p.numItrMinres) == (5.0, 25, 10, 1e-6, 500)
     assert (p.epsPcg, p.numItrPcg) == (1e-6, 1000)
     assert C.sizeof(_lib.QpsParams) == 8 * 4 + 9 * 8 + 4 * 4
-    assert C.sizeof(_lib.QpsInfo) == 4 * 4 + 7 * 8 + 2 * 4 + 8
+    assert C.sizeof(_lib.QpsInfo) == 4 * 4 + 7 * 8 + 2 * 4 + 8 + 2 * 4
     assert C.sizeof(_lib.QpsPolishReport) == 6 * 4 + 2 * 8
 
 
