@@ -162,9 +162,11 @@ def test_mode_auto_follows_the_reference_rule(gpu, c_oracle):
     assert info["cgIterations"] > 0 and int(flag) in (2, 3)
     xd, fd = gpu.SolveQuadraticProgram(P, q, A, l, u, linearSolverMode=gpu.LinearSolverMode.modeDirect, numIterations=4000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
     assert int(fd) == int(flag) and np.abs(x - xd).max() <= 1e-4 * max(1.0, np.abs(xd).max())
-    # dense n = 64, m = 128: 192 rows but density 1 > 0.4 -> iterative by the literal rule
+    # dense arrays: n = 64, m = 128 has (64^2 + 128 * 64) / 192^2 = 0.33 <= 0.4 -> direct (dense Cholesky); n = 64, m = 32 has 0.67 -> iterative
     from quadraticprogramsolver_amd.generator import GenerateDenseBenchmarkQP
     Pd, qd, Ad, ld, ud = GenerateDenseBenchmarkQP(64, 128, stream=3, feasible=True)
+    assert gpu.AutoLinearSolverMode(Pd, Ad) == gpu.LinearSolverMode.modeDirect
+    Pd, qd, Ad, ld, ud = GenerateDenseBenchmarkQP(64, 32, stream=3, feasible=True)
     assert gpu.AutoLinearSolverMode(Pd, Ad) == gpu.LinearSolverMode.modeItertaive
 
 
