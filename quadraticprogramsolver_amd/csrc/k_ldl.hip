@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void k_spanel(T* __restrict__ M, int64_t ld, i
 
 template <typename T> struct DevVec {
     T* p = nullptr; int64_t n = 0;
-    void alloc(int64_t count) { n = count; p = dalloc<T>(count); }
-    void upload(const std::vector<T>& h) { alloc((int64_t)h.size()); if (!h.empty()) HIPC(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice)); }
+    void alloc(int64_t count, hipStream_t st) { n = count; p = dalloc<T>(count, st); }
+    void upload(const std::vector<T>& h, StagedUploader& up) { alloc((int64_t)h.size(), up.st); if (!h.empty()) up.copy(p, h.data(), sizeof(T) * h.size()); }
     ~DevVec() { if (p) (void)hipFree(p); }
 };
 
@@ -241,29 +241,30 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
 
     SparseLdlImpl(hipStream_t st_, LdlSymbolic&& sym, const double* Pv, int64_t pnnz, const double* Av, int64_t annz) : st(st_), S(std::move(sym)) {
         const int N = S.N, Ns = S.Ns, Nt = S.Nt, ldt = S.ldt;
-        rp.upload(S.rp); ci.upload(S.ci); cp.upload(S.cp); ri.upload(S.ri);
+        StagedUploader up(st);   // host arrays -> device on the handle's own stream (qps_internal.h, stream-ordering rule)
+        rp.upload(S.rp, up); ci.upload(S.ci, up); cp.upload(S.cp, up); ri.upload(S.ri, up);
         {
             std::vector<int> cjv(S.ri.size()), inv(S.ri.size());
             for (int j = 0; j < Ns; ++j) for (int q = S.cp[j]; q < S.cp[j + 1]; ++q) cjv[q] = j;
             for (size_t k = 0; k < S.csr2csc.size(); ++k) inv[S.csr2csc[k]] = (int)k;
-            cj.upload(cjv); csc2csr.upload(inv);
+            cj.upload(cjv, up); csc2csr.upload(inv, up);
         }
-        kdst.upload(S.k_dst); ksrc.upload(S.k_src); dposP.upload(S.dpos_P); sign.upload(S.sign); perm.upload(S.perm); iperm.upload(S.iperm);
+        kdst.upload(S.k_dst, up); ksrc.upload(S.k_src, up); dposP.upload(S.dpos_P, up); sign.upload(S.sign, up); perm.upload(S.perm, up); iperm.upload(S.iperm, up);
         {
             std::vector<T> kv((size_t)(pnnz + annz));
             for (int64_t k = 0; k < pnnz; ++k) kv[k] = (T)Pv[k];
             for (int64_t k = 0; k < annz; ++k) kv[pnnz + k] = (T)Av[k];
-            kval.upload(kv);
+            kval.upload(kv, up);
         }
         const int64_t nz = (int64_t)S.ci.size();
-        vr.alloc(nz); vc.alloc(nz); D0.alloc(N); D.alloc(N); Dinv.alloc(N); b.alloc(N); fail.alloc(4);
-        tb.alloc(ldt + 64); tu.alloc(ldt + 64); tx.alloc(ldt + 64);
+        vr.alloc(nz, st); vc.alloc(nz, st); D0.alloc(N, st); D.alloc(N, st); Dinv.alloc(N, st); b.alloc(N, st); fail.alloc(4, st);
+        tb.alloc(ldt + 64, st); tu.alloc(ldt + 64, st); tx.alloc(ldt + 64, st);
         if (ldt > 0) {
             const int64_t tt = (int64_t)ldt * ldt;
-            Mt.alloc(tt); St.alloc(tt); tmp.alloc(tt); dinv.alloc((int64_t)(ldt / 64) * 4096);
+            Mt.alloc(tt, st); St.alloc(tt, st); tmp.alloc(tt, st); dinv.alloc((int64_t)(ldt / 64) * 4096, st);
             std::vector<T> sg(ldt, T(1));
             for (int i = 0; i < Nt; ++i) { sg[i] = (T)S.sign[Ns + i]; if (S.sign[Ns + i] < 0) tail_signed = true; }
-            tsgn.upload(sg);
+            tsgn.upload(sg, up);
             nb = 64; while (nb < ldt) nb *= 2;                                     // one inverted block covers the whole tail
             // chunks of tail-touching sparse columns for the Schur complement GEMM
             std::vector<int> tcol_first(Ns, -1); int ntc = 0;
@@ -282,8 +283,8 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
                 if (++kk == KC) { chunk_ptr.push_back((int)eq.size()); kk = 0; }
             }
             if (kk > 0) chunk_ptr.push_back((int)eq.size());
-            ent_q.upload(eq); ent_dst.upload(ed);
-            if (chunk_ptr.size() > 1) { Ld.alloc((int64_t)ldt * KC); Wd.alloc((int64_t)ldt * KC); }
+            ent_q.upload(eq, up); ent_dst.upload(ed, up);
+            if (chunk_ptr.size() > 1) { Ld.alloc((int64_t)ldt * KC, st); Wd.alloc((int64_t)ldt * KC, st); }
         }
         const int L = (int)S.level_ptr.size() - 1;
         lpr_fwd.assign(std::max(L, 0), 1); lpr_bwd.assign(std::max(L, 0), 1);
@@ -293,7 +294,6 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
             lpr_bwd[l] = pick_lpr((int64_t)S.cp[c1] - S.cp[c0], c1 - c0);
         }
         lpr_tail = pick_lpr((int64_t)S.rp[N] - S.rp[Ns], Nt);
-        HIPC(hipDeviceSynchronize());   // uploads above used the null stream; everything from here on is ordered on `st`
     }
     const LdlSymbolic& symbolic() const override { return S; }
     int launches_per_solve() const override { const int L = (int)S.level_ptr.size() - 1; return 2 + std::max(L - 1, 0) + L + (S.Nt > 0 ? 3 + (tail_signed ? 1 : 0) : 0); }

@@ -353,7 +353,7 @@ struct Csr {
 };
 
 template <typename T> struct SparseSolver : SolverBase {
-    HandleResources res;
+    HandleResources res; std::unique_ptr<StagedUploader> up;   // `up` lives for the duration of the constructor only
     Csr A, At, P, PA;   // PA = [P; A] stacked, column-blocked only: P u and A u of the CG operator from ONE pass over u
     T *q = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr;
     T *xx = nullptr, *zz = nullptr, *w = nullptr, *tt = nullptr, *cu = nullptr, *cu2 = nullptr, *cr = nullptr, *cc = nullptr, *tm = nullptr;
@@ -412,14 +412,14 @@ template <typename T> struct SparseSolver : SolverBase {
         M.wpb = std::max(M.wpb, (maxt + BMAXT - 1) / BMAXT);            // at most BMAXT tasks per workgroup
         M.per = (maxt + M.wpb - 1) / M.wpb;
         M.lpr4 = (M.nnz <= (int64_t)8 * nrows * nblk) ? 1 : 0;          // short row segments: 4 lanes per row
-        M.brp = dalloc<int>((int64_t)brp.size()); M.bci = dalloc<unsigned short>((int64_t)bci.size()); M.bva = dalloc<T>((int64_t)bva.size());
-        M.task_ptr = dalloc<int>(nblk + 1); M.tasks = dalloc<int4>((int64_t)tk.size() + 1);
-        M.partial = dalloc<T>((int64_t)nblk * nrows);
-        HIPC(hipMemcpy(M.brp, brp.data(), sizeof(int) * brp.size(), hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(M.bci, bci.data(), sizeof(unsigned short) * bci.size(), hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(M.bva, bva.data(), sizeof(T) * bva.size(), hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(M.task_ptr, tptr.data(), sizeof(int) * tptr.size(), hipMemcpyHostToDevice));
-        if (!tk.empty()) HIPC(hipMemcpy(M.tasks, tk.data(), sizeof(int4) * tk.size(), hipMemcpyHostToDevice));
+        M.brp = dalloc<int>((int64_t)brp.size(), st); M.bci = dalloc<unsigned short>((int64_t)bci.size(), st); M.bva = dalloc<T>((int64_t)bva.size(), st);
+        M.task_ptr = dalloc<int>(nblk + 1, st); M.tasks = dalloc<int4>((int64_t)tk.size() + 1, st);
+        M.partial = dalloc<T>((int64_t)nblk * nrows, st);
+        up->copy(M.brp, brp.data(), sizeof(int) * brp.size());
+        up->copy(M.bci, bci.data(), sizeof(unsigned short) * bci.size());
+        up->copy(M.bva, bva.data(), sizeof(T) * bva.size());
+        up->copy(M.task_ptr, tptr.data(), sizeof(int) * tptr.size());
+        if (!tk.empty()) up->copy(M.tasks, tk.data(), sizeof(int4) * tk.size());
         M.blocked = true;
     }
     void upload_csr(Csr& M, int nrows, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
@@ -429,8 +429,8 @@ template <typename T> struct SparseSolver : SolverBase {
             const bool want = e ? atoi(e) != 0 : M.nnz >= 200000;
             if (want && nrows > 0 && ncols > 0) build_blocked(M, ncols, rp, ci, va);
         }
-        M.rp = dalloc<int>(nrows + 1); M.ci = dalloc<int>(M.nnz); M.va = dalloc<T>(M.nnz);
-        HIPC(hipMemcpy(M.rp, rp.data(), sizeof(int) * (nrows + 1), hipMemcpyHostToDevice));
+        M.rp = dalloc<int>(nrows + 1, st); M.ci = dalloc<int>(M.nnz, st); M.va = dalloc<T>(M.nnz, st);
+        up->copy(M.rp, rp.data(), sizeof(int) * (nrows + 1));
         {   // row blocks of the CSR-stream kernel: consecutive rows with <= STREAM_NNZ non-zeros; a longer row stands alone
             std::vector<int> rbv(1, 0);
             int start = 0;
@@ -440,13 +440,13 @@ template <typename T> struct SparseSolver : SolverBase {
             }
             if (start < nrows) rbv.push_back(nrows);
             M.nblocks = (int)rbv.size() - 1;
-            M.rb = dalloc<int>((int64_t)rbv.size());
-            HIPC(hipMemcpy(M.rb, rbv.data(), sizeof(int) * rbv.size(), hipMemcpyHostToDevice));
+            M.rb = dalloc<int>((int64_t)rbv.size(), st);
+            up->copy(M.rb, rbv.data(), sizeof(int) * rbv.size());
         }
         if (M.nnz > 0) {
-            HIPC(hipMemcpy(M.ci, ci.data(), sizeof(int) * M.nnz, hipMemcpyHostToDevice));
+            up->copy(M.ci, ci.data(), sizeof(int) * M.nnz);
             std::vector<T> v(va.begin(), va.end());
-            HIPC(hipMemcpy(M.va, v.data(), sizeof(T) * M.nnz, hipMemcpyHostToDevice));
+            up->copy(M.va, v.data(), sizeof(T) * M.nnz);
         }
     }
     void upload_vec(const double* h, T* d, int64_t count) {
@@ -506,6 +506,7 @@ template <typename T> struct SparseSolver : SolverBase {
         res = acquire_resources(device, 0);   // recycled stream + pinned block (qps_internal.h)
         st = res.st;
         prof.st = st;
+        up.reset(new StagedUploader(st));
         const int64_t pnnz = Pcp[n] - base, annz = Acp[n] - base;
         if (pnnz > 2000000000LL || annz > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 non-zeros");
         // P: CSC == CSR (symmetric, full storage).  A': rows of A' are the columns of A == the caller's CSC.
@@ -537,17 +538,17 @@ template <typename T> struct SparseSolver : SolverBase {
             build_blocked(PA, (int)n, srp, sci, sva);
         }
         const int64_t nn = n + 64, mm = m + 64;
-        q = dalloc<T>(nn); x = dalloc<T>(nn); xp = dalloc<T>(nn); xx = dalloc<T>(nn); tt = dalloc<T>(nn);
-        cu = dalloc<T>(nn); cu2 = dalloc<T>(nn); cr = dalloc<T>(nn); cc = dalloc<T>(nn); Px = dalloc<T>(nn); Aty = dalloc<T>(nn);
-        l = dalloc<T>(mm); u = dalloc<T>(mm); z = dalloc<T>(mm); zp = dalloc<T>(mm); y = dalloc<T>(mm); zz = dalloc<T>(mm);
-        w = dalloc<T>(mm); tm = dalloc<T>(mm); Ax = dalloc<T>(mm);
+        q = dalloc<T>(nn, st); x = dalloc<T>(nn, st); xp = dalloc<T>(nn, st); xx = dalloc<T>(nn, st); tt = dalloc<T>(nn, st);
+        cu = dalloc<T>(nn, st); cu2 = dalloc<T>(nn, st); cr = dalloc<T>(nn, st); cc = dalloc<T>(nn, st); Px = dalloc<T>(nn, st); Aty = dalloc<T>(nn, st);
+        l = dalloc<T>(mm, st); u = dalloc<T>(mm, st); z = dalloc<T>(mm, st); zp = dalloc<T>(mm, st); y = dalloc<T>(mm, st); zz = dalloc<T>(mm, st);
+        w = dalloc<T>(mm, st); tm = dalloc<T>(mm, st); Ax = dalloc<T>(mm, st);
         nb_n = (int)((n + 255) / 256);
-        part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n) + 64); part_rr = dalloc<double>(nb_n + 64);
-        state = reinterpret_cast<CgState*>(dalloc<double>(16));
+        part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n) + 64, st); part_rr = dalloc<double>(nb_n + 64, st);
+        state = reinterpret_cast<CgState*>(dalloc<double>(16, st));
         state_host = reinterpret_cast<CgState*>(res.pinned);                          // pinned block: CG state | check results
-        scratch = dalloc<unsigned long long>(16); res_dev = dalloc<double>(16);
+        scratch = dalloc<unsigned long long>(16, st); res_dev = dalloc<double>(16, st);
         res_host = reinterpret_cast<double*>(reinterpret_cast<char*>(res.pinned) + 128);
-        stage = dalloc<double>(std::max(nn, mm) + 64);
+        stage = dalloc<double>(std::max(nn, mm) + 64, st);
         upload_vec(qh, q, n); upload_vec(lh, l, m); upload_vec(uh, u, m);
         const double s = sizeof(T);
         auto spmv_bytes = [&](const Csr& M, int cols) { return (double)M.nnz * (s + 4) + M.nrows * 4.0 + s * (M.nrows + cols); };
@@ -559,9 +560,8 @@ template <typename T> struct SparseSolver : SolverBase {
         // the dominant kernel of the CG path: the stacked [P; A] product (nnz * 12 + rows * 4 + s * (rows + cols))
         cat_pa = prof.category("spmv_blk([P;A] u, x block in LDS)", (double)(pnnz + annz) * (s + 4) + (double)(n + m) * 4.0 + s * (double)(n + m + n));
         cat_at = prof.category("spmv_blk(A' v, x block in LDS)", spmv_bytes(At, (int)m));
-        // The CSR arrays went up with synchronous hipMemcpy from pageable memory: that returns once the data is staged, the DMA
-        // may still be running on the null stream, and the solver stream is not ordered against it.
-        HIPC(hipDeviceSynchronize());
+        // every fill and every upload above was enqueued on `st` (qps_internal.h, stream-ordering rule): nothing to wait for here
+        up.reset();
     }
     ~SparseSolver() override {
         (void)hipSetDevice(device);

@@ -138,7 +138,7 @@ template <typename T> struct DenseSolver : SolverBase {
         layout(arena);
         res = acquire_resources(device, arena.planned());                    // stream, pinned block and maybe a recycled device block
         st = res.st; prof.st = st;
-        try { arena.commit(res.block, res.block_bytes); }
+        try { arena.commit(st, res.block, res.block_bytes); }
         catch (...) { recycle_resources(device, res); res = HandleResources(); st = nullptr; prof.st = nullptr; throw; }
         res.block = nullptr;                                                  // owned by the arena from here on
         layout(arena);
@@ -506,23 +506,23 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         }
         part_tiles = gemv_cols_tiles(MP);
         const int64_t nn = (int64_t)NP * NP, c = count;
-        A = dalloc<T>(c * MP * NP); P = dalloc<T>(c * nn); PI = dalloc<T>(c * nn); AA = dalloc<T>(c * nn); M = dalloc<T>(c * nn);
-        S = dalloc<T>(c * nn); tmp = dalloc<T>(c * nn); dinv = dalloc<T>(c * (int64_t)(NP / 64) * 4096);
-        q = dalloc<T>(c * NP); l = dalloc<T>(c * MP); u = dalloc<T>(c * MP);
-        x = dalloc<T>(c * NP); xp = dalloc<T>(c * NP); xres = dalloc<T>(c * NP); xx = dalloc<T>(c * NP); tt = dalloc<T>(c * NP);
-        yv = dalloc<T>(c * NP); Px = dalloc<T>(c * NP); Aty = dalloc<T>(c * NP); z = dalloc<T>(c * MP); y = dalloc<T>(c * MP);
+        A = dalloc<T>(c * MP * NP, st); P = dalloc<T>(c * nn, st); PI = dalloc<T>(c * nn, st); AA = dalloc<T>(c * nn, st); M = dalloc<T>(c * nn, st);
+        S = dalloc<T>(c * nn, st); tmp = dalloc<T>(c * nn, st); dinv = dalloc<T>(c * (int64_t)(NP / 64) * 4096, st);
+        q = dalloc<T>(c * NP, st); l = dalloc<T>(c * MP, st); u = dalloc<T>(c * MP, st);
+        x = dalloc<T>(c * NP, st); xp = dalloc<T>(c * NP, st); xres = dalloc<T>(c * NP, st); xx = dalloc<T>(c * NP, st); tt = dalloc<T>(c * NP, st);
+        yv = dalloc<T>(c * NP, st); Px = dalloc<T>(c * NP, st); Aty = dalloc<T>(c * NP, st); z = dalloc<T>(c * MP, st); y = dalloc<T>(c * MP, st);
         // polishing (one QP at a time) writes the slabs of a count = 1 pass plan, or the tiles of the column GEMV, into `part`:
         // count * slabs can be smaller than either (count = 3, NP = 2048: 246 < 256)
         int rpw1 = 0;
         const int64_t part_slabs = std::max<int64_t>(std::max<int64_t>(c * slabs, apass_plan<T>(NP, MP, &rpw1, 1)), std::max(part_tiles, 1));
-        part = dalloc<T>(part_slabs * NP); part2 = dalloc<T>(c * slabs * NP); part_tmp = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
-        sw_slabs = sweep_fused_slabs<T>(NP, count); sw_part = dalloc<T>(c * std::max(sw_slabs, 1) * NP);
-        fail = dalloc<int>(count + 4); d_active = dalloc<int>(count + 4); d_rho = dalloc<double>(count + 4); d_rhorho = dalloc<double>(count + 4);
-        scratch = dalloc<unsigned long long>(16 * c); res_dev = dalloc<double>(8 * c);
+        part = dalloc<T>(part_slabs * NP, st); part2 = dalloc<T>(c * slabs * NP, st); part_tmp = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP, st);
+        sw_slabs = sweep_fused_slabs<T>(NP, count); sw_part = dalloc<T>(c * std::max(sw_slabs, 1) * NP, st);
+        fail = dalloc<int>(count + 4, st); d_active = dalloc<int>(count + 4, st); d_rho = dalloc<double>(count + 4, st); d_rhorho = dalloc<double>(count + 4, st);
+        scratch = dalloc<unsigned long long>(16 * c, st); res_dev = dalloc<double>(8 * c, st);
         HIPC(hipHostMalloc((void**)&res_host, 8 * c * sizeof(double)));
         HIPC(hipHostMalloc((void**)&h_int, (count + 4) * sizeof(int)));
         HIPC(hipHostMalloc((void**)&h_dbl, 2 * (count + 4) * sizeof(double)));
-        stage = dalloc<double>(std::max<int64_t>((int64_t)MP * NP, nn) + 64);
+        stage = dalloc<double>(std::max<int64_t>((int64_t)MP * NP, nn) + 64, st);
     }
     ~BatchedDenseSolver() override {
         (void)hipSetDevice(device);
@@ -632,7 +632,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             // Small shapes: ONE workgroup per QP runs that QP's whole loop (register-resident kernel, k_small.hip); the host only
             // steps in when some QP wants a rho switch (refactor, relaunch from its own iteration) -- SolveQuadraticProgram.jl:45-71 per QP.
             const size_t ab = admm_small_args_bytes(), ob = admm_small_out_bytes();
-            if (!sb_args) { sb_args = dalloc<char>((int64_t)(ab + ob) * count + 64); HIPC(hipHostMalloc(&sb_host, (ab + ob) * (size_t)count + 64)); }
+            if (!sb_args) { sb_args = dalloc<char>((int64_t)(ab + ob) * count + 64, st); HIPC(hipHostMalloc(&sb_host, (ab + ob) * (size_t)count + 64)); }
             char* args_h = static_cast<char*>(sb_host); char* outs_h = args_h + ab * count;
             char* args_d = sb_args; char* outs_d = sb_args + ab * count;
             std::vector<int> it(count, 0);

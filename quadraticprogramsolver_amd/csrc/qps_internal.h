@@ -77,15 +77,50 @@ struct ProfScope {
         }                                                                                                     \
     } while (0)
 
-template <typename T> inline T* dalloc(int64_t count) {
+// Stream-ordering rule of the library: a handle works on its own NON-BLOCKING stream, which is not ordered against the null stream.
+// Nothing a handle's kernels read is therefore ever written through the null stream: zero fills are hipMemsetAsync on the
+// handle's stream, host data arrives through StagedUploader (pinned staging + hipMemcpyAsync on the same stream), and every later
+// kernel of the handle is enqueued on that stream too -- the order "fill -> upload -> first use" is the stream's own order, no
+// device-wide synchronisation stands in for it.  (Round 1 zero-filled with hipMemset and uploaded with synchronous hipMemcpy
+// from pageable memory: both run on the null stream and may still be in flight when the call returns.  Without the waits that
+// were bolted on afterwards, a fill could land after an import kernel of the solver stream had written the same buffer -- the
+// "Cholesky breakdown on a well-conditioned matrix" seen once -- and the first SpMV could read CSR arrays whose DMA had not
+// finished -- the run-to-run differences of CG iteration counts.)
+template <typename T> inline T* dalloc(int64_t count, hipStream_t st) {
     T* p = nullptr; if (count < 64) count = 64;
     HIPC(hipMalloc((void**)&p, sizeof(T) * (size_t)count));
-    HIPC(hipMemset(p, 0, sizeof(T) * (size_t)count));
-    // The fill runs on the null stream and may still be in flight when hipMemset returns; the solver streams are
-    // non-blocking (not ordered against the null stream), so wait here: a kernel must never race the zero fill.
-    HIPC(hipStreamSynchronize(nullptr));
+    HIPC(hipMemsetAsync(p, 0, sizeof(T) * (size_t)count, st));
     return p;
 }
+
+// Pageable host memory -> device, ordered on `st`: the bytes travel through a pinned double buffer; a half is reused only after the
+// copy that read it has completed (its event), so the caller's source may be freed as soon as copy() returns.
+struct StagedUploader {
+    hipStream_t st; char* pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
+    size_t cap; int cur = 0;
+    explicit StagedUploader(hipStream_t s, size_t cap_ = (size_t)8 << 20) : st(s), cap(cap_) {}
+    StagedUploader(const StagedUploader&) = delete;
+    ~StagedUploader() {
+        for (int k = 0; k < 2; ++k) {
+            if (busy[k]) (void)hipEventSynchronize(ev[k]);
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            if (pin[k]) (void)hipHostFree(pin[k]);
+        }
+    }
+    void copy(void* dst, const void* src, size_t bytes) {
+        const char* s_ = static_cast<const char*>(src); char* d_ = static_cast<char*>(dst);
+        while (bytes > 0) {
+            const int k = cur; cur ^= 1;
+            if (!pin[k]) { HIPC(hipHostMalloc((void**)&pin[k], cap)); HIPC(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
+            if (busy[k]) { HIPC(hipEventSynchronize(ev[k])); busy[k] = false; }
+            const size_t nb = bytes < cap ? bytes : cap;
+            memcpy(pin[k], s_, nb);
+            HIPC(hipMemcpyAsync(d_, pin[k], nb, hipMemcpyHostToDevice, st));
+            HIPC(hipEventRecord(ev[k], st)); busy[k] = true;
+            s_ += nb; d_ += nb; bytes -= nb;
+        }
+    }
+};
 
 // One device allocation per handle: thirty-odd hipMalloc + zero-fill + hipFree calls cost ~4.5 ms per handle, ten times the
 // solve itself at the reference's test sizes.  Lay the buffers out twice: once against a null base to add up the sizes, once for real.
@@ -101,12 +136,11 @@ struct Arena {
     size_t bytes = 0;
     size_t planned() const { return ((off + 255) & ~(size_t)255) + 256; }
     // allocate what the planning pass added up (or adopt a recycled block of at least that size), zero it, restart the layout for real
-    void commit(char* recycled = nullptr, size_t recycled_bytes = 0) {
+    void commit(hipStream_t st, char* recycled = nullptr, size_t recycled_bytes = 0) {
         const size_t need = planned();
         if (recycled) { base = recycled; bytes = recycled_bytes; }
         else { HIPC(hipMalloc((void**)&base, need)); bytes = need; }
-        HIPC(hipMemset(base, 0, need));
-        HIPC(hipStreamSynchronize(nullptr));   // the fill runs on the null stream; the solver streams are not ordered against it
+        HIPC(hipMemsetAsync(base, 0, need, st));   // on the handle's stream: ordered before everything the handle enqueues later
         off = 0; planning = false;
     }
     void release() { if (base) (void)hipFree(base); base = nullptr; }

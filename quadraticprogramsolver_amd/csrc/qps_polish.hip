@@ -236,11 +236,11 @@ void polish_with(hipStream_t st, int64_t n, int64_t m, int NP, int MP, const T* 
     if (p.numItrPolish <= 0) { if (rep) *rep = r; return; }                                        // :292
     const int N = NP + MP;
     PolishWork<T> wk;
-    wk.base = dalloc<T>((int64_t)10 * N + MP);
+    wk.base = dalloc<T>((int64_t)10 * N + MP, st);
     T* g = wk.base; T* t = g + N; T* tt = t + N; T* rhs = tt + N; T* c = rhs + N; T* Ra = c + N; T* Rb = Ra + N;
     T* W[3] = {Rb + N, Rb + 2 * (int64_t)N, Rb + 3 * (int64_t)N}; T* mask = Rb + 4 * (int64_t)N;
     const int nb = (N + 255) / 256;
-    wk.pa = dalloc<double>(nb); wk.pb = dalloc<double>(nb); wk.state = dalloc<MrState>(2); wk.counts = dalloc<int>(4);
+    wk.pa = dalloc<double>(nb, st); wk.pb = dalloc<double>(nb, st); wk.state = dalloc<MrState>(2, st); wk.counts = dalloc<int>(4, st);
     HIPC(hipHostMalloc((void**)&wk.state_host, sizeof(MrState)));
     hipLaunchKernelGGL((k_pol_setup<T>), blocks(std::max(NP, MP)), dim3(256), 0, st, (int)n, NP, (int)m, MP, q, l, u, y, mask, g, wk.counts);
     int counts[2] = {0, 0};

@@ -106,16 +106,16 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         mtot = (int)(me + mi);
         NP = roundup(n, 64); MP = roundup(mtot, 64); MEP = roundup(std::max<int64_t>(me, 1), 64);
         const int64_t nn = (int64_t)NP * NP;
-        G = dalloc<T>((int64_t)MP * NP); Aonly = dalloc<T>((int64_t)MEP * NP); P = dalloc<T>(nn); q = dalloc<T>(NP); x = dalloc<T>(NP);
-        g = dalloc<T>(MP); dual = dalloc<T>(MP); slack = dalloc<T>(MP); w = dalloc<T>(MP); v = dalloc<T>(MP); de = dalloc<T>(MP); di = dalloc<T>(MP);
-        tt = dalloc<T>(NP); yv = dalloc<T>(NP); xx = dalloc<T>(NP); X1 = dalloc<T>(NP); X2 = dalloc<T>(NP); X3 = dalloc<T>(NP);
+        G = dalloc<T>((int64_t)MP * NP, st); Aonly = dalloc<T>((int64_t)MEP * NP, st); P = dalloc<T>(nn, st); q = dalloc<T>(NP, st); x = dalloc<T>(NP, st);
+        g = dalloc<T>(MP, st); dual = dalloc<T>(MP, st); slack = dalloc<T>(MP, st); w = dalloc<T>(MP, st); v = dalloc<T>(MP, st); de = dalloc<T>(MP, st); di = dalloc<T>(MP, st);
+        tt = dalloc<T>(NP, st); yv = dalloc<T>(NP, st); xx = dalloc<T>(NP, st); X1 = dalloc<T>(NP, st); X2 = dalloc<T>(NP, st); X3 = dalloc<T>(NP, st);
         part_tiles = std::max(gemv_cols_tiles(MP), apass_proxqp_slabs<T>(NP, MP));
-        part = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP);
-        sw_part = dalloc<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
-        PI = dalloc<T>(nn); KK = dalloc<T>(nn); M = dalloc<T>(nn); S = dalloc<T>(nn); tmp = dalloc<T>(nn); dinv = dalloc<T>((int64_t)(NP / 64) * 4096);
-        fail = dalloc<int>(4); slots = dalloc<unsigned long long>(16);
+        part = dalloc<T>((int64_t)std::max(part_tiles, 1) * NP, st);
+        sw_part = dalloc<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP, st);
+        PI = dalloc<T>(nn, st); KK = dalloc<T>(nn, st); M = dalloc<T>(nn, st); S = dalloc<T>(nn, st); tmp = dalloc<T>(nn, st); dinv = dalloc<T>((int64_t)(NP / 64) * 4096, st);
+        fail = dalloc<int>(4, st); slots = dalloc<unsigned long long>(16, st);
         slots_host = reinterpret_cast<unsigned long long*>(res.pinned);
-        stage = dalloc<double>(std::max<int64_t>((int64_t)MP * NP, nn) + 64);
+        stage = dalloc<double>(std::max<int64_t>((int64_t)MP * NP, nn) + 64, st);
     }
     ~ProxQpSolver() override {
         (void)hipSetDevice(device);

@@ -193,6 +193,19 @@ def test_proxqp_defaults_are_the_reference_defaults(qps):
     assert (p.numIterations, p.epsAbs, p.epsRel, p.numItrConv, p.rho, p.sigma, p.adptRho, p.tau) == (2000, 1e-7, 1e-6, 50, 1e2, 1e-2, 1, 10.0)
 
 
+def test_no_null_stream_fills_or_uploads_in_the_library():
+    """Stream-ordering rule (qps_internal.h): handles work on non-blocking streams, so nothing their kernels read may be written
+    through the null stream.  Synchronous hipMemset / hipMemcpy, waits on the null stream and device-wide synchronisations that
+    would paper over such a write are banned from the sources altogether."""
+    csrc = os.path.join(ROOT, "quadraticprogramsolver_amd", "csrc")
+    banned = re.compile(r"\bhipMemset\s*\(|\bhipMemcpy\s*\(|hipStreamSynchronize\s*\(\s*(nullptr|0|NULL)\s*\)|\bhipDeviceSynchronize\s*\(|\bhipMemcpy2D\s*\(")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            code = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f), errors="ignore").read())
+            hit = banned.search(code)
+            assert hit is None, f"{f}: {hit.group(0)}"
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under the package or include/ may reference it."""
     pkg = os.path.join(ROOT, "quadraticprogramsolver_amd")
