@@ -33,6 +33,9 @@ struct HipCholInitT end;  const HipCholInit = HipCholInitT()      # dense reduce
 struct HipCholT end;      const HipChol! = HipCholT()
 struct HipCgInitT end;    const HipCgInit = HipCgInitT()          # CSR matrix-free CG on the device
 struct HipCgT end;        const HipCg! = HipCgT()
+struct HipLdlInitT end;   const HipLdlInit = HipLdlInitT()        # sparse L D L' of the KKT matrix on the device: the counterpart of
+struct HipLdlT end;       const HipLdl! = HipLdlT()               # LaLdlInit/LaLdl!, QDLdlInit/QDLdl!, FacLdlInit/FacLdl! (LinearSystemSolvers.jl:16-107)
+const QPS_LINSYS_CHOLESKY = Int32(1); const QPS_LINSYS_CG = Int32(2); const QPS_LINSYS_KKT_LDL = Int32(3)
 
 function _check(status::Int32, h::Ptr{Cvoid} = C_NULL)
     status == 0 && return
@@ -64,13 +67,13 @@ function _create(mP::Matrix{Float64}, vQ, mA::Matrix{Float64}, vL, vU; densePath
     return h[]
 end
 
-function _solve!(vX::Vector{Float64}, mP, vQ, mA, vL, vU, densePath::Bool;
+function _solve!(vX::Vector{Float64}, mP, vQ, mA, vL, vU, densePath::Bool, linsys::Int32 = densePath ? QPS_LINSYS_CHOLESKY : QPS_LINSYS_CG;
     numIterations = 5000, ϵAbs = 1e-6, ϵRel = 1e-6, ρ = 1, σ = 1e-6, α = 1.6, δ = 1e-6, adptΡ::Bool = false,
     fctrΡ = 5, numItrConv = 25, numItrPolish = 10, ϵMinres = 1e-6, numItrMinres = 500, info = nothing,
     polish::Bool = false)   # polish = true: the polishing step of SolveQuadraticProgram.m:289-325 (the Julia loop reserves its kwargs unused)
     h = _create(mP, Vector{Float64}(vQ), mA, Vector{Float64}(vL), Vector{Float64}(vU); densePath = densePath)
     try
-        prm = QpsParams(numIterations, adptΡ, numItrConv, numItrPolish, numItrMinres, densePath ? 1 : 2, 0, 0,
+        prm = QpsParams(numIterations, adptΡ, numItrConv, numItrPolish, numItrMinres, linsys, 0, 0,
                         ϵAbs, ϵRel, ρ, σ, α, δ, fctrΡ, ϵMinres, 1e-6, 1000, 0, polish, 0)
         inf = QpsInfo()
         GC.@preserve vX _check(ccall((:qps_solve, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{QpsParams}, Ref{QpsInfo}),
@@ -85,6 +88,16 @@ end
 # Same positional order and keyword names as SolveQuadraticProgram.jl:14-17
 SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipCholInitT, ::HipCholT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, true; kw...)
 SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipCgInitT, ::HipCgT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, false; kw...)
+# RunTests.jl:55-56 / RunBenchmarks.jl:54-55 select FacLdlInit / FacLdl!; the device counterpart takes the same SparseMatrixCSC inputs
+SolveQuadraticProgram!(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, vL, vU, ::HipLdlInitT, ::HipLdlT; kw...) =
+    _solve!(vX, mP, vQ, mA, vL, vU, false, QPS_LINSYS_KKT_LDL; kw...)
+
+# modeAuto of SolveQuadraticProgramRef! (SolveQuadraticProgram.jl:143-151), evaluated by the library so that every binding shares one rule
+function AutoLinearSystemPair(mP, mA)
+    sparseIn = (mP isa SparseMatrixCSC) && (mA isa SparseMatrixCSC)
+    kind = ccall((:qps_linsys_auto, LIBQPS), Int32, (Int64, Int64, Int64, Int64, Int32), size(mP, 1), size(mA, 1), nnz(sparse(mP)), nnz(sparse(mA)), Int32(sparseIn))
+    return kind == QPS_LINSYS_CG ? (HipCgInit, HipCg!) : (kind == QPS_LINSYS_KKT_LDL ? (HipLdlInit, HipLdl!) : (HipCholInit, HipChol!))
+end
 
 # Convenience form named in the project brief: SolveQuadraticProgram(P, q, A, l, u; ...) -> (x, flag)
 function SolveQuadraticProgram(mP, vQ, mA, vL, vU; kw...)
@@ -107,6 +120,16 @@ function (::HipCholInitT)(vX, mP, vQ, mA, ρ, ρ¹, σ, numElements, numConstrai
     _check(ccall((:qps_linsys_init, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Float64, Int32, Int32), h, ρ, σ, 1, 0), h)
     return zeros(numElements), zeros(numConstraints), Any[HipLinSys(h)]
 end
+# the direct KKT plugins' literal signature (LinearSystemSolvers.jl:16,28): Init factorises [mP + σI  mA'; mA  -ρ¹I] on the device (ordering +
+# symbolic once), Sol! re-factorises numerically on changedΡ and solves
+function (::HipLdlInitT)(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, ρ, ρ¹, σ, numElements, numConstraints)
+    h = _create(mP, Vector{Float64}(vQ), mA, zeros(numConstraints), zeros(numConstraints); densePath = false)
+    _check(ccall((:qps_linsys_init, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Float64, Int32, Int32), h, ρ, σ, QPS_LINSYS_KKT_LDL, 0), h)
+    return zeros(numElements), zeros(numConstraints), Any[HipLinSys(h)]
+end
+(::HipLdlT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ) =
+    HipChol!(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ)   # same qps_linsys_solve call
+
 function (::HipCholT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ)
     h = tuSolver[1].h
     GC.@preserve vXX vZZ vX vZ vY _check(ccall((:qps_linsys_solve, LIBQPS), Int32,

@@ -20,7 +20,7 @@ namespace {
 // accumulation.  The triangle is read once (n(n+1)/2 elements instead of n(n+1)); each workgroup leaves a slab of
 // column sums that colsum() adds in fixed order.  Same structure as the fused A-pass (k_pass.hip).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int THREADS, int KC, int RB>
+template <typename T, int THREADS, int KC, int RB, bool DB = true>   // DB: double-buffered tiles (the wide variants KC > 8 keep one tile: registers)
 __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S, int64_t ld, int NP, const T* __restrict__ v,
                                                          T* __restrict__ part, int64_t part_ld, BatchStride bs) {
     using V = typename VecOf<T>::type;
@@ -96,18 +96,23 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
         }
     };
     const int my_tiles = (ntiles - g + G - 1) / G;
-    if (my_tiles > 0) {
-        V bufA[RB][KC], bufB[RB][KC];
-        load(bufA, tile_row(0));
-        for (int it = 0; it < my_tiles; it += 2) {
-            const bool haveB = it + 1 < my_tiles;
-            if (haveB) load(bufB, tile_row(it + 1));
-            process(bufA, tile_row(it), 0);
-            if (haveB) {
-                if (it + 2 < my_tiles) load(bufA, tile_row(it + 2));
-                process(bufB, tile_row(it + 1), 1);
+    if constexpr (DB) {
+        if (my_tiles > 0) {
+            V bufA[RB][KC], bufB[RB][KC];
+            load(bufA, tile_row(0));
+            for (int it = 0; it < my_tiles; it += 2) {
+                const bool haveB = it + 1 < my_tiles;
+                if (haveB) load(bufB, tile_row(it + 1));
+                process(bufA, tile_row(it), 0);
+                if (haveB) {
+                    if (it + 2 < my_tiles) load(bufA, tile_row(it + 2));
+                    process(bufB, tile_row(it + 1), 1);
+                }
             }
         }
+    } else {
+        V buf[RB][KC];
+        for (int it = 0; it < my_tiles; ++it) { load(buf, tile_row(it)); process(buf, tile_row(it), it & 1); }
     }
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
@@ -132,12 +137,13 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
 
 }  // namespace
 
-template <typename T> bool sweep_fused_supported(int NP) { return NP <= 8 * 512 * VecOf<T>::N && NP >= 1024; }
+template <typename T> bool sweep_fused_supported(int NP) { return NP <= 16 * 512 * VecOf<T>::N && NP >= 1024; }   // 16384 fp64 / 32768 fp32
 
 static int sweep_rb() { static int rb = [] { const char* e = getenv("QPS_SWEEP_RB"); return e ? atoi(e) : 2; }(); return rb; }   // fp64: 2-row tiles measured best
 
 template <typename T> int sweep_fused_slabs(int NP, int count) {
-    const int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
+    int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
+    if (NP > 8 * 512 * VecOf<T>::N) RB = 1;   // wide single-buffered variants
     static const int total_env = [] { const char* e = getenv("QPS_SWEEP_WGS"); return e ? atoi(e) : 0; }();
     const int kc = (NP + 512 * VecOf<T>::N - 1) / (512 * VecOf<T>::N);
     const int total = total_env > 0 ? total_env : (count <= 1 ? 256 : (kc <= 1 ? 1024 : (kc == 2 ? 512 : 256)));   // batches: by register footprint
@@ -162,8 +168,15 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
         if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused<T, TH, KC, RB>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \
         else hipLaunchKernelGGL((k_sweep_fused<T, TH, KC, RB>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs);            \
     } while (0)
-    if (rb2) { if (kc <= 1) QPS_S(1, 2); else if (kc <= 2) QPS_S(2, 2); else if (kc <= 4) QPS_S(4, 2); else QPS_S(8, 2); }
+#define QPS_SW(KC)                                                                                                                 \
+    do {                                                                                                                           \
+        if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused<T, TH, KC, 1, false>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \
+        else hipLaunchKernelGGL((k_sweep_fused<T, TH, KC, 1, false>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs);      \
+    } while (0)
+    if (kc > 8) { if (kc <= 12) QPS_SW(12); else QPS_SW(16); }
+    else if (rb2) { if (kc <= 1) QPS_S(1, 2); else if (kc <= 2) QPS_S(2, 2); else if (kc <= 4) QPS_S(4, 2); else QPS_S(8, 2); }
     else     { if (kc <= 1) QPS_S(1, 4); else if (kc <= 2) QPS_S(2, 4); else if (kc <= 4) QPS_S(4, 4); else QPS_S(8, 2 * (VecOf<T>::N / 2)); }
+#undef QPS_SW
 #undef QPS_S
     return G;
 }

@@ -55,8 +55,9 @@ namespace {
 
 thread_local std::string g_last_error;
 
-int pick_nb(int requested, int NP) {
-    int nb = requested > 0 ? requested : 4096;
+int pick_nb(int requested, int NP, bool cover = false) {
+    // default: one inverted block over the whole factor while the fused forward+backward sweep covers NP (`cover`), else 4096
+    int nb = requested > 0 ? requested : (cover ? 32768 : 4096);
     int p = 64; while (p * 2 <= nb) p *= 2;   // power-of-two multiple of 64
     nb = p;
     while (nb > 64 && nb / 2 >= NP) nb /= 2;
@@ -287,7 +288,7 @@ template <typename T> struct DenseSolver : SolverBase {
         if (p.linsys != QPS_LINSYS_AUTO && p.linsys != QPS_LINSYS_CHOLESKY)
             throw QpsError(QPS_ERR_UNSUPPORTED, "dense handles offer QPS_LINSYS_CHOLESKY only (qps_create_csc with dense_path = 0 for the CG and the sparse L D L' plugins)");
         const double t0 = now_s();
-        nb = pick_nb(p.trsvBlock, NP);
+        nb = pick_nb(p.trsvBlock, NP, sweep_fused_supported<T>(NP));
         double rho = p.rho, sigma = p.sigma; const double alpha = p.alpha;
         const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;                                // SolveQuadraticProgram.jl:34
         int convFlag = QPS_CONV_NUM_ITR;                                                            // :33
@@ -453,7 +454,7 @@ template <typename T> struct DenseSolver : SolverBase {
     void linsys_init(double rho, double sigma, int linsys, int nbreq) override {
         HIPC(hipSetDevice(device));
         if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "dense handles support QPS_LINSYS_CHOLESKY only");
-        nb = pick_nb(nbreq, NP);
+        nb = pick_nb(nbreq, NP, sweep_fused_supported<T>(NP));
         factorize(rho, sigma, true);
     }
     void linsys_solve(const double* xh, const double* zh, const double* yh, double rho, double sigma, int changed,
@@ -600,7 +601,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         HIPC(hipSetDevice(device));
         const double t0 = now_s();
         if (slabs <= 0) throw QpsError(QPS_ERR_UNSUPPORTED, "batched path needs m >= 1 and n within the fused-pass limit");
-        nb = pick_nb(p.trsvBlock, NP);
+        nb = pick_nb(p.trsvBlock, NP, sweep_fused_supported<T>(NP));
         const double sigma = p.sigma, alpha = p.alpha;
         const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;
         std::vector<double> rho(count, p.rho), rhorho(count, p.rho), resP(count, NAN), resD(count, NAN), tref(count, 0.0);

@@ -76,6 +76,35 @@ int main(void) {
         ok = ok && qr.converged && viol <= 1e-5;
         qps_destroy(hp);
     }
+    /* the same known-answer problem as Julia-style CSC arrays (1-based Int64 colptr / rowval) through the sparse direct KKT plugin
+     * (QPS_LINSYS_KKT_LDL: LaLdl / QDLdl / FacLdl of LinearSystemSolvers.jl:16-107), after the host-only symbolic analysis */
+    {
+        int64_t cp[N + 1], ri[N], perm[2 * N]; double pv[N], av[N], xs[N] = {0};
+        for (int i = 0; i < N; ++i) { cp[i] = i + 1; ri[i] = i + 1; pv[i] = 1.0 + 0.5 * i; av[i] = 1.0; }
+        cp[N] = N + 1;
+        qps_ldl_report lr;
+        rc = qps_ldl_analyze(N, N, cp, ri, cp, ri, 1, perm, &lr);
+        if (rc != QPS_OK) { fprintf(stderr, "ldl_analyze failed: %s\n", qps_last_error(NULL)); return 1; }
+        ok = ok && lr.numRows == 2 * N && lr.numSparseColumns + lr.tailSize == 2 * N && lr.nnzK == N && lr.nnzL == N;   /* K = [D I; I -I/rho]: no fill */
+        ok = ok && qps_linsys_auto(N, N, N, N, 1) == QPS_LINSYS_KKT_LDL && qps_linsys_auto(3000, 2001, N, N, 1) == QPS_LINSYS_CG;
+        qps_handle hs = NULL;
+        rc = qps_create_csc(N, N, cp, ri, pv, cp, ri, av, q, l, u, 1, /*dense_path*/0, QPS_F64, 0, &hs);
+        if (rc != QPS_OK) { fprintf(stderr, "create_csc failed: %s\n", qps_last_error(NULL)); return 1; }
+        qps_params ps = prm; ps.linsys = QPS_LINSYS_KKT_LDL; ps.rho = 0.1; ps.adptRho = 1;
+        rc = qps_solve(hs, xs, &ps, &info);
+        if (rc != QPS_OK) { fprintf(stderr, "ldl solve failed: %s\n", qps_last_error(hs)); return 1; }
+        double dl = 0.0;
+        for (int i = 0; i < N; ++i) dl = fmax(dl, fabs(xs[i] - xstar[i]));
+        printf("kkt ldl: flag=%d iterations=%d refactor=%d max|x-x*|=%.3e (sparse columns %lld, dense tail %lld)\n", info.convFlag, info.iterations,
+               info.numRefactor, dl, (long long)lr.numSparseColumns, (long long)lr.tailSize);
+        ok = ok && dl <= 1e-5 && info.cgIterations == 0;
+        /* an asymmetric P is refused like MATLAB's issymmetric check (SolveQuadraticProgram.m:166-168) */
+        double Pbad[N * N]; for (int i = 0; i < N * N; ++i) Pbad[i] = P[i];
+        Pbad[1] = 1e-3;                                                       /* (1, 0) without its mirror image */
+        qps_handle hx = NULL;
+        ok = ok && qps_create_dense(N, N, Pbad, N, A, N, q, l, u, QPS_F64, 0, &hx) == QPS_ERR_BAD_ARGUMENT && hx == NULL;
+        qps_destroy(hs);
+    }
     /* error path: a non-positive-definite problem must be reported, not hidden */
     qps_handle hb = NULL;
     for (int i = 0; i < N; ++i) P[i + i * N] = -1.0;

@@ -430,14 +430,17 @@ def test_benchmark_solvers_driver(gpu, tmp_path):
     assert len(table) == 7 and table[0][0] == "Solver"
 
 
-def test_large_n_falls_back_to_unfused_kernels(gpu):
-    """n beyond the register-tile limit of the fused kernels (NP > 8192 in fp64): unfused loop, three sweep blocks with a
-    ragged last one.  Checked through size-independent properties (linear-solve residual, reported residuals)."""
+def test_large_n_keeps_the_fused_kernels(gpu):
+    """n beyond 8192 (fp64): the fused A-pass switches to its 1024-thread instantiation and the fused forward+backward sweep to its
+    wide single-buffered one (NP <= 16384), with one inverted block over the whole factor (trsvBlock = 16384, ragged doubling).
+    Checked through size-independent properties (linear-solve residual, reported residuals), against the unfused kernel order
+    (loopVariant = 1: A read twice, blocked substitution with three sweep blocks) and against plain blocked substitution."""
     n, m = 9000, 3000
     rng = make_rng(31, 0)
     d = rng.random(n) + 0.5
     U = rng.standard_normal((n, 8)) / np.sqrt(n)
     P = np.diag(d) + U @ U.T                       # SPD, cheap to build and to multiply
+    P = 0.5 * (P + P.T)
     A = rng.standard_normal((m, n)) / np.sqrt(n)
     q = rng.standard_normal(n); l = -rng.random(m); u = rng.random(m)
     with gpu.QuadraticProgram(P, q, A, l, u) as prob:
@@ -449,6 +452,14 @@ def test_large_n_falls_back_to_unfused_kernels(gpu):
         rhs = sigma * x - q + A.T @ (rho * z - y)
         lhs = P @ xx + sigma * xx + rho * (A.T @ (A @ xx))
         assert np.abs(lhs - rhs).max() <= 1e-10 * max(1.0, np.abs(rhs).max())
+        runs = {}
+        for tag, kw in (("fused", dict()), ("unfused", dict(loopVariant=1, trsvBlock=4096)), ("substitution", dict(trsvBlock=64))):
+            xk = np.zeros(n); info = {}
+            prob.solve(xk, numIterations=50, ϵAbs=0.0, ϵRel=0.0, ρ=rho, info=info, **kw)
+            runs[tag] = (xk, info)
+        assert runs["fused"][1]["sweepVariant"] == 2 and runs["fused"][1]["trsvBlock"] == 16384
+        assert runs["unfused"][1]["sweepVariant"] == 1 and runs["substitution"][1]["trsvBlock"] == 64
+        assert rel(runs["fused"][0], runs["unfused"][0]) <= 1e-9 and rel(runs["fused"][0], runs["substitution"][0]) <= 1e-9
         xk = np.zeros(n); info = {}
         flag = prob.solve(xk, numIterations=2000, ϵAbs=1e-6, ϵRel=1e-6, ρ=rho, adptΡ=True, info=info)
         zk, yk = prob.dual()
