@@ -215,6 +215,13 @@ int32_t qps_proxqp_default_params(qps_proxqp_params *p);
 int32_t qps_proxqp_create_dense(int64_t n, int64_t numEq, int64_t numInEq, const double *P, int64_t ldp, const double *q,
                                 const double *A, int64_t lda, const double *b, const double *C, int64_t ldc, const double *d,
                                 int32_t dtype, int32_t device, qps_handle *out);
+/* SparseProxQP (ProxQP.jl:71, :95-115): the same with the colptr / rowval / nzval fields of three SparseMatrixCSC inputs (index_base 1 for
+ * Julia).  The matrices are densified and take the dense path; the in-place dense re-factorisation (ProxQP.jl:193-199) stands in for the
+ * pattern-reusing sparse cholesky! of :201-206. */
+int32_t qps_proxqp_create_csc(int64_t n, int64_t numEq, int64_t numInEq, const int64_t *P_colptr, const int64_t *P_rowval, const double *P_nzval,
+                              const double *q, const int64_t *A_colptr, const int64_t *A_rowval, const double *A_nzval, const double *b,
+                              const int64_t *C_colptr, const int64_t *C_rowval, const double *C_nzval, const double *d, int32_t index_base,
+                              int32_t dtype, int32_t device, qps_handle *out);
 int32_t qps_proxqp_init_kkt(qps_handle h);
 int32_t qps_proxqp_set_state(qps_handle h, const double *x, const double *y, const double *z, const double *s);
 int32_t qps_proxqp_get_state(qps_handle h, double *x, double *y, double *z, double *s);

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
     "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
     "qps_proxqp_default_params", "qps_proxqp_create_dense", "qps_proxqp_init_kkt", "qps_proxqp_set_state", "qps_proxqp_get_state",
-    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze",
+    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze", "qps_proxqp_create_csc",
 ]
 
 QPS_OK = 0
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
     L.qps_set_profiling.argtypes = [hp, i32]
     L.qps_proxqp_default_params.argtypes = [C.POINTER(QpsProxQpParams)]
     L.qps_proxqp_create_dense.argtypes = [i64, i64, i64, dp, i64, dp, dp, i64, dp, dp, i64, dp, i32, i32, C.POINTER(hp)]
+    L.qps_proxqp_create_csc.argtypes = [i64, i64, i64, ip, ip, dp, dp, ip, ip, dp, dp, ip, ip, dp, dp, i32, i32, i32, C.POINTER(hp)]
     L.qps_proxqp_init_kkt.argtypes = [hp]
     L.qps_proxqp_set_state.argtypes = [hp, dp, dp, dp, dp]
     L.qps_proxqp_get_state.argtypes = [hp, dp, dp, dp, dp]

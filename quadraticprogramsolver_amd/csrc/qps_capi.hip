@@ -1152,6 +1152,41 @@ QPS_API int32_t qps_proxqp_create_dense(int64_t n, int64_t me, int64_t mi, const
     *out = reinterpret_cast<qps_handle>(h);
     return QPS_OK;
 }
+// SparseProxQP (ProxQP.jl:71, :95-115): the CSC fields of the three SparseMatrixCSC inputs.  The matrices are densified and take the dense
+// path: M = P + sigma I + rho (A'A + C'C) is factorised as a dense matrix and re-factorised in place on a rho change (ProxQP.jl:193-199),
+// which stands in for the pattern-reusing sparse cholesky! of :201-206 (and makes GetNzvalDiagIdxs / AlignSparsePattern, :335-372, moot).
+QPS_API int32_t qps_proxqp_create_csc(int64_t n, int64_t me, int64_t mi, const int64_t* Pcp, const int64_t* Pri, const double* Pnz, const double* q,
+                                      const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* b, const int64_t* Ccp, const int64_t* Cri,
+                                      const double* Cnz, const double* d, int32_t index_base, int32_t dtype, int32_t device, qps_handle* out) {
+    if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
+    *out = nullptr;
+    if (n <= 0 || me < 0 || mi < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1, numEq >= 0, numInEq >= 0");
+    if (n > (1 << 16) || me + mi > (1 << 20)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "problem too large to densify");
+    if (!Pcp || !q || (me > 0 && (!Acp || !b)) || (mi > 0 && (!Ccp || !d))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
+    if (index_base != 0 && index_base != 1) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "index_base must be 0 or 1");
+    std::vector<double> Pd, Ad, Cd;
+    auto densify = [&](const int64_t* cp, const int64_t* ri, const double* nz, int64_t rows, std::vector<double>& D, const char* name) -> int {
+        D.assign((size_t)std::max<int64_t>(rows, 1) * n, 0.0);
+        if (rows == 0) return QPS_OK;
+        if (cp[0] != index_base) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, std::string(name) + ": colptr does not start at index_base");
+        for (int64_t j = 0; j < n; ++j) {
+            if (cp[j + 1] < cp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, std::string(name) + ": colptr not monotone");
+            for (int64_t k = cp[j] - index_base; k < cp[j + 1] - index_base; ++k) {
+                const int64_t i = ri[k] - index_base;
+                if (i < 0 || i >= rows) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, std::string(name) + ": row index out of range");
+                D[(size_t)i + (size_t)j * rows] += nz[k];
+            }
+        }
+        return QPS_OK;
+    };
+    int rc = guarded(nullptr, [&] {
+        int r = densify(Pcp, Pri, Pnz, n, Pd, "mP"); if (r == QPS_OK) r = densify(Acp, Ari, Anz, me, Ad, "mA"); if (r == QPS_OK) r = densify(Ccp, Cri, Cnz, mi, Cd, "mC");
+        if (r != QPS_OK) throw QpsError(r, g_last_error);
+    });
+    if (rc != QPS_OK) return rc;
+    return qps_proxqp_create_dense(n, me, mi, Pd.data(), n, q, me > 0 ? Ad.data() : nullptr, std::max<int64_t>(me, 1), b, mi > 0 ? Cd.data() : nullptr,
+                                   std::max<int64_t>(mi, 1), d, dtype, device, out);
+}
 QPS_API int32_t qps_proxqp_init_kkt(qps_handle hh) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!h || !h->proxqp) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "not a ProxQP handle");

@@ -28,18 +28,28 @@ class ProxQP:
     (ProxQP.jl:73-93); ``ProxQP(mP, vQ, mA, vB, mC, vD, vX, vY, vZ, vS)`` takes the state explicitly (ProxQP.jl:36)."""
 
     def __init__(self, mP, vQ, mA, vB, mC, vD, vX=None, vY=None, vZ=None, vS=None, *, dtype="f64", device=0):
-        dense = lambda M: np.asfortranarray(M.toarray() if sp.issparse(M) else M, dtype=np.float64)
-        P, A, Cm = dense(mP), dense(mA), dense(mC)
-        self.dataDim, self.numEq, self.numInEq = P.shape[0], A.shape[0], Cm.shape[0]          # ProxQP.jl:39-41
+        self.dataDim, self.numEq, self.numInEq = mP.shape[0], mA.shape[0], mC.shape[0]        # ProxQP.jl:39-41
         n, me, mi = self.dataDim, self.numEq, self.numInEq
-        if P.shape != (n, n) or (me and A.shape[1] != n) or (mi and Cm.shape[1] != n):
+        if mP.shape != (n, n) or (me and mA.shape[1] != n) or (mi and mC.shape[1] != n):
             raise ValueError("dimension mismatch between mP, mA and mC")
         vec = lambda v, k, name: self._vec(v, k, name)
         q, b, d = vec(vQ, n, "vQ"), vec(vB, me, "vB"), vec(vD, mi, "vD")
         h = C.c_void_p()
         dt = {"f64": QPS_F64, "f32": QPS_F32}[dtype]
-        _lib.check(_lib.lib().qps_proxqp_create_dense(n, me, mi, _dp(P), max(n, 1), _dp(q), _dp(A), max(me, 1), _dp(b), _dp(Cm), max(mi, 1),
-                                                      _dp(d), dt, device, C.byref(h)))
+        if sp.issparse(mP) and sp.issparse(mA) and sp.issparse(mC):                            # SparseProxQP (ProxQP.jl:71, :95-115): CSC fields as they are
+            ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+            csc = []
+            for M in (mP, mA, mC):
+                Mc = sp.csc_matrix(M, dtype=np.float64); Mc.sum_duplicates()
+                csc.append((Mc.indptr.astype(np.int64), Mc.indices.astype(np.int64), np.ascontiguousarray(Mc.data)))
+            (Pc, Pr, Pv), (Ac, Ar, Av), (Cc, Cr, Cv) = csc
+            _lib.check(_lib.lib().qps_proxqp_create_csc(n, me, mi, ip(Pc), ip(Pr), _dp(Pv), _dp(q), ip(Ac), ip(Ar), _dp(Av), _dp(self._pad(b)), ip(Cc), ip(Cr),
+                                                        _dp(Cv), _dp(self._pad(d)), 0, dt, device, C.byref(h)))
+        else:
+            dense = lambda M: np.asfortranarray(M.toarray() if sp.issparse(M) else M, dtype=np.float64)
+            P, A, Cm = dense(mP), dense(mA), dense(mC)
+            _lib.check(_lib.lib().qps_proxqp_create_dense(n, me, mi, _dp(P), max(n, 1), _dp(q), _dp(A), max(me, 1), _dp(b), _dp(Cm), max(mi, 1),
+                                                          _dp(d), dt, device, C.byref(h)))
         self._h = h
         self.vX, self.vY, self.vZ, self.vS = np.zeros(n), np.zeros(me), np.zeros(mi), np.zeros(mi)
         if vX is None:

@@ -103,3 +103,26 @@ def test_error_behaviour(gpu):
     with gpu.ProxQP(P, q, A2, b2, C, d, np.zeros(40), np.zeros(11), np.zeros(30), np.zeros(30)) as prob:   # explicit state: no KKT solve needed
         rep = gpu.SolveQuadraticProgramProxQP(prob, numIterations=200)
         assert np.isfinite(rep["PrimalResidual"])
+
+
+def test_sparse_constructor_equals_dense_constructor(gpu, po):
+    """SparseProxQP (ProxQP.jl:71, :95-115): SparseMatrixCSC inputs through qps_proxqp_create_csc give the same initial state and the
+    same state after the loop as the dense constructor on the same matrices (including a rho update) and as the oracle."""
+    import scipy.sparse as sp
+    rng = make_rng(1517, 3)
+    n, me, mi = 120, 30, 90
+    M = sp.random(n, n, density=0.1, random_state=np.random.default_rng(5), data_rvs=rng.standard_normal).toarray()
+    P = M.T @ M + 0.01 * np.eye(n); P = 0.5 * (P + P.T)
+    A = sp.random(me, n, density=0.2, random_state=np.random.default_rng(6), data_rvs=rng.standard_normal).toarray()
+    C = sp.random(mi, n, density=0.2, random_state=np.random.default_rng(7), data_rvs=rng.standard_normal).toarray()
+    q = rng.standard_normal(n); x0 = rng.standard_normal(n); b = A @ x0; d = C @ x0 + 0.2
+    kw = dict(numIterations=300, ρ=1e2, σ=1e-2, adptΡ=True)
+    with gpu.ProxQP(sp.csc_matrix(P), q, sp.csc_matrix(A), b, sp.csc_matrix(C), d) as ps, gpu.ProxQP(P, q, A, b, C, d) as pd:
+        assert rel(ps.vX, pd.vX) <= 1e-12 and rel(ps.vY, pd.vY) <= 1e-12 and rel(ps.vS, pd.vS) <= 1e-12
+        rs = gpu.SolveQuadraticProgramProxQP(ps, **kw)
+        rd = gpu.SolveQuadraticProgramProxQP(pd, **kw)
+        assert rs == rd
+        assert rel(ps.vX, pd.vX) <= 1e-12 and rel(ps.vZ, pd.vZ) <= 1e-12
+        ref = po.ProxQP.from_problem(P, q, A, b, C, d)
+        po.SolveQuadraticProgramProxQP(ref, **kw)
+        assert rel(ps.vX, ref.vX) <= 1e-7
