@@ -117,6 +117,13 @@ template <typename T, int LPR> __device__ __forceinline__ T group_sum(T s) {
     if (LPR == 4) return quad_sum_all(s);
     if (LPR == 16) return row16_sum_last(s);       // valid in the last lane of the group
     if (LPR == 64) return wave_sum_all(s);
+    if (LPR == 256) {                              // one workgroup per row / column (long tail rows): wave sums, then a fixed-order sum of the four
+        __shared__ T wsum4[4];
+        s = wave_sum_all(s);
+        if ((threadIdx.x & 63) == 0) wsum4[threadIdx.x >> 6] = s;
+        __syncthreads();
+        return (wsum4[0] + wsum4[1]) + (wsum4[2] + wsum4[3]);
+    }
     return s;
 }
 // forward substitution for the rows [r0, r1) of one level (or of the tail): b_r -= sum_k L_rk b_k, all k in earlier levels
@@ -154,6 +161,38 @@ __global__ __launch_bounds__(256) void k_ldl_post(int n, int m, int Ns, const in
     const T v = k >= Ns ? tx[k - Ns] : b[k];
     if (o < n) xx[o] = v;
     else { const int r = o - n; zz[r] = z[r] + rho1 * (v - y[r]); }           // LinearSystemSolvers.jl:40  nu -> z~
+}
+
+// un-permute, nu -> z~ (LinearSystemSolvers.jl:40), the ADMM updates (SolveQuadraticProgram.jl:56-61, same expressions as k_admm_update) and
+// the permuted right-hand side of the NEXT iteration (LinearSystemSolvers.jl:37-38) in one launch; thread o owns entry o of [x; nu]
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_post_update(int n, int m, int Ns, const int* __restrict__ iperm, T* __restrict__ b, const T* __restrict__ tx,
+                                                         const T* __restrict__ q, T* __restrict__ x, T* __restrict__ xp, T* __restrict__ z, T* __restrict__ zp,
+                                                         T* __restrict__ y, const T* __restrict__ l, const T* __restrict__ u, T alpha, T rho, T sigma) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n + m) return;
+    const int k = iperm[o];
+    const T v = k >= Ns ? tx[k - Ns] : b[k];                                   // entry o of the solution: every thread reads its own b[k] before it overwrites it
+    const T alpha1 = T(1) - alpha, rho1 = T(1) / rho;
+    if (o < n) {
+        const T xo = x[o];
+        xp[o] = xo;                                                           // :56
+        const T xn = alpha * v + alpha1 * xo;                                 // :57
+        x[o] = xn;
+        b[k] = sigma * xn - q[o];                                             // next :37
+    } else {
+        const int r = o - n;
+        const T zo = z[r], yo = y[r];
+        const T zt = zo + rho1 * (v - yo);                                    // LinearSystemSolvers.jl:40  nu -> z~
+        zp[r] = zo;                                                           // :59
+        const T t = alpha * zt + alpha1 * zo + rho1 * yo;                     // :60
+        const T lo = l[r], hi = u[r];
+        const T zn = t > hi ? hi : (t < lo ? lo : t);
+        z[r] = zn;
+        const T yn = yo + rho * (alpha * zt + alpha1 * zo - zn);              // :61
+        y[r] = yn;
+        b[k] = zn - rho1 * yn;                                                // next :38
+    }
 }
 
 // ---- dense signed Cholesky of the tail (one 64-column step = diagonal block, panel, MFMA trailing update) -----------------
@@ -227,7 +266,7 @@ template <typename T> struct DevVec {
 int pick_lpr(int64_t nnz, int rows) {
     if (rows <= 0) return 1;
     const double avg = (double)nnz / rows;
-    return avg <= 2.0 ? 1 : (avg <= 12.0 ? 4 : (avg <= 96.0 ? 16 : 64));
+    return avg <= 2.0 ? 1 : (avg <= 12.0 ? 4 : (avg <= 96.0 ? 16 : (avg <= 1024.0 || rows > 2048 ? 64 : 256)));
 }
 
 template <typename T> struct SparseLdlImpl : SparseLdl<T> {
@@ -345,16 +384,14 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
     template <int LPR> void fwd_launch(int r0, int r1) {
         hipLaunchKernelGGL((k_ldl_fwd<T, LPR>), dim3((unsigned)(((int64_t)(r1 - r0) * LPR + 255) / 256)), dim3(256), 0, st, r0, r1, S.Ns, rp.p, ci.p, vr.p, b.p, tb.p);
     }
-    void fwd(int r0, int r1, int lpr) { if (r1 <= r0) return; if (lpr == 1) fwd_launch<1>(r0, r1); else if (lpr == 4) fwd_launch<4>(r0, r1); else if (lpr == 16) fwd_launch<16>(r0, r1); else fwd_launch<64>(r0, r1); }
+    void fwd(int r0, int r1, int lpr) { if (r1 <= r0) return; if (lpr == 1) fwd_launch<1>(r0, r1); else if (lpr == 4) fwd_launch<4>(r0, r1); else if (lpr == 16) fwd_launch<16>(r0, r1); else if (lpr == 64) fwd_launch<64>(r0, r1); else fwd_launch<256>(r0, r1); }
     template <int LPR> void bwd_launch(int c0, int c1) {
         hipLaunchKernelGGL((k_ldl_bwd<T, LPR>), dim3((unsigned)(((int64_t)(c1 - c0) * LPR + 255) / 256)), dim3(256), 0, st, c0, c1, S.Ns, cp.p, ri.p, vc.p, Dinv.p, b.p, tx.p);
     }
-    void bwd(int c0, int c1, int lpr) { if (c1 <= c0) return; if (lpr == 1) bwd_launch<1>(c0, c1); else if (lpr == 4) bwd_launch<4>(c0, c1); else if (lpr == 16) bwd_launch<16>(c0, c1); else bwd_launch<64>(c0, c1); }
+    void bwd(int c0, int c1, int lpr) { if (c1 <= c0) return; if (lpr == 1) bwd_launch<1>(c0, c1); else if (lpr == 4) bwd_launch<4>(c0, c1); else if (lpr == 16) bwd_launch<16>(c0, c1); else if (lpr == 64) bwd_launch<64>(c0, c1); else bwd_launch<256>(c0, c1); }
 
-    void solve(const T* x, const T* q, const T* z, const T* y, double rho, double sigma, T* xx, T* zz) override {
+    void sweeps() {   // b (permuted right-hand side) -> solution in b (sparse part) and tx (tail)
         const int N = S.N, Ns = S.Ns, Nt = S.Nt, ldt = S.ldt;
-        const T rho1 = (T)(1.0 / rho);
-        hipLaunchKernelGGL((k_ldl_rhs<T>), dim3((N + 255) / 256), dim3(256), 0, st, N, S.n, perm.p, x, q, z, y, (T)sigma, rho1, b.p);
         const int L = (int)S.level_ptr.size() - 1;
         for (int l = 1; l < L; ++l) fwd(S.level_ptr[l], S.level_ptr[l + 1], lpr_fwd[l]);          // level 0: leaves, nothing to subtract
         if (Nt > 0) {
@@ -364,7 +401,20 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
             gemv_rows<T>(st, St.p, ldt, tu.p, tx.p, nullptr, T(1), T(0), 0, ldt, 0, ldt, 2);        // inv(Lt)' .
         }
         for (int l = L - 1; l >= 0; --l) bwd(S.level_ptr[l], S.level_ptr[l + 1], lpr_bwd[l]);
-        hipLaunchKernelGGL((k_ldl_post<T>), dim3((N + 255) / 256), dim3(256), 0, st, S.n, S.m, Ns, iperm.p, b.p, tx.p, z, y, rho1, xx, zz);
+    }
+    void iterate(T* x, T* xp, const T* q, T* z, T* zp, T* y, const T* l, const T* u, double alpha, double rho, double sigma, bool rhs_ready) override {
+        const int N = S.N;
+        if (!rhs_ready) hipLaunchKernelGGL((k_ldl_rhs<T>), dim3((N + 255) / 256), dim3(256), 0, st, N, S.n, perm.p, x, q, z, y, (T)sigma, (T)(1.0 / rho), b.p);
+        sweeps();
+        hipLaunchKernelGGL((k_ldl_post_update<T>), dim3((N + 255) / 256), dim3(256), 0, st, S.n, S.m, S.Ns, iperm.p, b.p, tx.p, q, x, xp, z, zp, y, l, u,
+                           (T)alpha, (T)rho, (T)sigma);
+    }
+    void solve(const T* x, const T* q, const T* z, const T* y, double rho, double sigma, T* xx, T* zz) override {
+        const int N = S.N;
+        const T rho1 = (T)(1.0 / rho);
+        hipLaunchKernelGGL((k_ldl_rhs<T>), dim3((N + 255) / 256), dim3(256), 0, st, N, S.n, perm.p, x, q, z, y, (T)sigma, rho1, b.p);
+        sweeps();
+        hipLaunchKernelGGL((k_ldl_post<T>), dim3((N + 255) / 256), dim3(256), 0, st, S.n, S.m, S.Ns, iperm.p, b.p, tx.p, z, y, rho1, xx, zz);
     }
 };
 

@@ -367,6 +367,26 @@ template <typename T> struct SparseSolver : SolverBase {
     std::vector<int64_t> hPcp, hPri, hAcp, hAri; std::vector<double> hPnz, hAnz;
     std::unique_ptr<SparseLdl<T>> ldl; bool ldl_valid = false; double ldl_rho = 0, ldl_sigma = 0; int plugin_kind = QPS_LINSYS_CG;
     int num_factorizations = 0;
+    // hipGraph replay of ONE plain iteration of the direct plugin (a dozen launches of 2-3 us of work each: the eager loop is bound by
+    // the host's launch rate).  Keyed by the scalars baked into the kernel arguments; every pointer of the loop is fixed.
+    struct IterGraph { double rho, sigma, alpha; hipGraphExec_t exec; };
+    std::vector<IterGraph> graphs; bool graphs_disabled = false;
+    void drop_graphs() { for (auto& gr : graphs) (void)hipGraphExecDestroy(gr.exec); graphs.clear(); }
+    hipGraphExec_t iter_graph(double rho, double sigma, double alpha) {
+        for (auto& gr : graphs) if (gr.rho == rho && gr.sigma == sigma && gr.alpha == alpha) return gr.exec;
+        if (graphs_disabled) return nullptr;
+        if (graphs.size() >= 8) drop_graphs();
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graphs_disabled = true; return nullptr; }
+        ldl->iterate(x, xp, q, z, zp, y, l, u, alpha, rho, sigma, true);                            // SolveQuadraticProgram.jl:54-61, right-hand side already in place
+        // nothing was enqueued while capturing, so a failure here just means: run this handle's iterations eagerly from now on
+        if (hipStreamEndCapture(st, &graph) != hipSuccess || graph == nullptr) { (void)hipGetLastError(); graphs_disabled = true; return nullptr; }
+        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { (void)hipGetLastError(); graphs_disabled = true; return nullptr; }
+        graphs.push_back({rho, sigma, alpha, exec});
+        return exec;
+    }
 
     // column-blocked copy for k_spmv_blk: per block a CSR with 16-bit local column indices + its task list
     void build_blocked(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
@@ -566,6 +586,7 @@ template <typename T> struct SparseSolver : SolverBase {
     ~SparseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
+        drop_graphs();
         if (cu2) (void)hipFree(cu2);
         for (Csr* M_ : {&A, &At, &P, &PA}) {
             void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial};
@@ -712,15 +733,28 @@ template <typename T> struct SparseSolver : SolverBase {
         double rhorho = rho; int ii = 0, nref = 0; double resP = NAN, resD = NAN, tref = 0;
         cg_total = 0; last_cg = 4;
         const int NPv = (int)n, MPv = (int)m;
+        static const int graph_env = [] { const char* e = getenv("QPS_GRAPH"); return e ? atoi(e) : -1; }();
+        const bool use_graph = plugin_kind == QPS_LINSYS_KKT_LDL && prof.level == 0 && graph_env != 0;
+        bool ldl_rhs_ready = false;   // the fused post/update launch leaves the next right-hand side behind; stale after a rho switch
         for (ii = 1; ii <= p.numIterations; ++ii) {
             if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {
                 rho = rhorho; ++nref;                                                               // CG: the operator is matrix-free, nothing to rebuild
-                if (plugin_kind == QPS_LINSYS_KKT_LDL) { const double ta = now_s(); ldl_prepare(rho, sigma, true); tref += now_s() - ta; }   // changedΡ: numeric refactor only
+                if (plugin_kind == QPS_LINSYS_KKT_LDL) { const double ta = now_s(); ldl_prepare(rho, sigma, true); tref += now_s() - ta; ldl_rhs_ready = false; }   // changedΡ: numeric refactor only
             }
+            if (plugin_kind == QPS_LINSYS_KKT_LDL && prof.level < 2) {
+                // direct plugin: sweeps + ONE launch for nu -> z~, the x / z / y updates and the next right-hand side (k_ldl_post_update)
+                if (use_graph && ldl_rhs_ready && ii % p.numItrConv != 0) {
+                    hipGraphExec_t ge = iter_graph(rho, sigma, alpha);
+                    if (ge) { HIPC(hipGraphLaunch(ge, st)); continue; }                             // a plain iteration: same kernels, same order
+                }
+                ldl->iterate(x, xp, q, z, zp, y, l, u, alpha, rho, sigma, ldl_rhs_ready);
+                ldl_rhs_ready = true;
+            } else {
             linear_solve(rho, sigma);
             {
                 ProfScope ps(prof, cat_vec, 2);
                 admm_update<T>(st, NPv, MPv, xx, zz, x, xp, z, zp, y, l, u, (T)alpha, (T)rho);
+            }
             }
             if (ii % p.numItrConv == 0) {
                 {

@@ -15,6 +15,11 @@ template <typename T> struct SparseLdl {
     virtual void factorize(double rho, double sigma) = 0;
     // LinSysSol! body (:37-40): rhs [sigma x - q; z - y / rho], solve in place, xx = x~, zz = z + (nu - y) / rho
     virtual void solve(const T* x, const T* q, const T* z, const T* y, double rho, double sigma, T* xx, T* zz) = 0;
+    // One whole ADMM iteration around the solve (SolveQuadraticProgram.jl:54-61): the sweeps, then ONE launch that un-permutes,
+    // forms z~ (:40), applies the x / z / y updates (:56-61) and writes the NEXT iteration's permuted right-hand side (:37-38) --
+    // two launches fewer per iteration than solve() + admm_update.  rhs_ready: the previous call of iterate() with the same
+    // (rho, sigma) already left the right-hand side in place.
+    virtual void iterate(T* x, T* xp, const T* q, T* z, T* zp, T* y, const T* l, const T* u, double alpha, double rho, double sigma, bool rhs_ready) = 0;
     virtual const LdlSymbolic& symbolic() const = 0;
     virtual int launches_per_solve() const = 0;
     virtual double bytes_per_solve() const = 0;

@@ -597,6 +597,11 @@ def test_tuning_knobs_do_not_change_results(gpu, knob, tmp_path):
         with q.QuadraticProgram(Ps, qs, As, ls, us, linsys="cg") as prob:
             prob.solve(x, numIterations=15, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, ϵPcg=1e-12, numItrPcg=3000)
         out["cg"] = x.tolist()
+        Pl, ql, Al, ll, ul = q.GenerateRandomQP(q.ProblemClass.lassoOptimization, 10, rng=q.make_rng(9, 9))
+        x = np.zeros(Pl.shape[0])
+        with q.QuadraticProgram(Pl, ql, Al, ll, ul, linsys="ldl") as prob:
+            prob.solve(x, numIterations=60, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
+        out["ldl"] = x.tolist()
         print(json.dumps(out))
     ''')
     f = tmp_path / "knob.py"; f.write_text(script)
