@@ -502,9 +502,9 @@ template <typename T> struct SparseSolver : SolverBase {
     void ldl_prepare(double rho, double sigma, bool force) {
         if (!ldl) {
             if (n + m > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "KKT matrix too large for the sparse direct plugin");
-            static const int max_tail = [] { const char* e = getenv("QPS_LDL_MAX_TAIL"); return e ? atoi(e) : 8192; }();
-            static const int min_level = [] { const char* e = getenv("QPS_LDL_MIN_LEVEL"); return e ? atoi(e) : 64; }();
-            static const int max_levels = [] { const char* e = getenv("QPS_LDL_MAX_LEVELS"); return e ? atoi(e) : 4096; }();
+            // read at every analysis (once per handle), not once per process: the limits are part of a handle's layout
+            const char *e1 = getenv("QPS_LDL_MAX_TAIL"), *e2 = getenv("QPS_LDL_MIN_LEVEL"), *e3 = getenv("QPS_LDL_MAX_LEVELS");
+            const int max_tail = e1 ? atoi(e1) : 8192, min_level = e2 ? atoi(e2) : 64, max_levels = e3 ? atoi(e3) : 4096;
             LdlSymbolic sym;
             try { sym = ldl_analyze((int)n, (int)m, hPcp.data(), hPri.data(), hAcp.data(), hAri.data(), 0, max_tail, min_level, max_levels); }
             catch (const std::runtime_error& e) { throw QpsError(QPS_ERR_UNSUPPORTED, e.what()); }

@@ -180,3 +180,58 @@ def test_ldl_refuses_what_it_cannot_hold(gpu):
         with pytest.raises(gpu.QpsError) as e:
             prob.solve(np.zeros(8))
         assert e.value.status == 8
+
+
+def _banded_problem(n, bw, rng):
+    """SPD band matrix P (half bandwidth bw) with chain constraints x_{i+1} - x_i in [-1, 1]: a deep, narrow elimination tree."""
+    diags = [rng.standard_normal(n - k) * 0.3 for k in range(1, bw + 1)]
+    P = sp.diags([np.full(n, 2.0 * bw)] + diags + diags, [0] + list(range(1, bw + 1)) + [-k for k in range(1, bw + 1)], format="csc")
+    A = sp.diags([-np.ones(n - 1), np.ones(n - 1)], [0, 1], shape=(n - 1, n), format="csc")
+    return P, rng.standard_normal(n), A, -np.ones(n - 1), np.ones(n - 1)
+
+
+@pytest.mark.parametrize("n,bw,env", [(3000, 2, {}), (3000, 2, {"QPS_LDL_MAX_TAIL": "256", "QPS_LDL_MIN_LEVEL": "8"}), (600, 5, {"QPS_LDL_MAX_TAIL": "64", "QPS_LDL_MIN_LEVEL": "2"})])
+def test_ldl_deep_elimination_tree(gpu, c_oracle, monkeypatch, n, bw, env):
+    """Banded P + chain constraints: the elimination tree is a few long chains, so most levels are narrow.  Default limits put them
+    into the dense tail; with a small tail limit the narrow levels stay sparse (one launch per level and sweep, hundreds of levels).
+    Both layouts must reproduce the oracle's iterates and solve."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)                         # read when the handle analyses its KKT matrix (first use of the plugin)
+    P, q, A, l, u = _banded_problem(n, bw, make_rng(91, n + bw))
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="ldl") as prob:
+        x = np.zeros(n); info = {}
+        prob.solve(x, numIterations=40, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+        xo, io = c_oracle.solve(P, q, A, l, u, numIterations=40, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+        assert rel(x, xo) <= 1e-9
+        x = np.zeros(n); info = {}
+        flag = prob.solve(x, numIterations=20000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True, info=info)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+    assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+    assert np.abs(x - xo).max() <= ABS_DEV_THR
+
+
+def test_ldl_refuses_a_tree_that_is_too_deep(gpu, monkeypatch):
+    """More sparse levels than QPS_LDL_MAX_LEVELS: explicit QPS_ERR_UNSUPPORTED naming the CG plugin (no silent fallback)."""
+    monkeypatch.setenv("QPS_LDL_MAX_TAIL", "64"); monkeypatch.setenv("QPS_LDL_MIN_LEVEL", "2"); monkeypatch.setenv("QPS_LDL_MAX_LEVELS", "16")
+    P, q, A, l, u = _banded_problem(2000, 1, make_rng(92, 0))
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="ldl") as prob:
+        with pytest.raises(gpu.QpsError) as e:
+            prob.solve(np.zeros(2000), numIterations=10)
+        assert e.value.status == 8 and "CG" in str(e.value)
+
+
+def test_ldl_large_sparse_problems(gpu, c_oracle):
+    """Beyond the reference's test sizes: portfolioOptimization n = 5000 (N = 5050, M = 5051, one dense constraint row, dense tail of 51)
+    and a sparse inequalityConstrainedQp (n = 1500, m = 3000) whose fill leaves a dense tail of 1400 columns -- solution-level parity
+    with the oracle's sparse L D L' (same flags, iteration and re-factorisation counts)."""
+    for pc, n, m, dens in ((ProblemClass.portfolioOptimization, 5000, 0, None), (ProblemClass.inequalityConstrainedQp, 1500, 3000, 0.004)):
+        P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(93, int(pc)), densityFctr=dens)
+        kw = dict(numIterations=20000, epsAbs=1e-6, epsRel=1e-6, rho=0.1, adptRho=True)
+        xo, io = c_oracle.solve(P, q, A, l, u, linsys=c_oracle.KIND_KKT_LDL_SPARSE, **kw)
+        x = np.zeros(P.shape[0]); info = {}
+        t0 = time.perf_counter()
+        flag = gpu.SolveQuadraticProgramInplace(x, P, q, A, l, u, gpu.HipLdlInit, gpu.HipLdl, numIterations=20000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True, info=info)
+        note(f"large {pc.name} N={P.shape[0]} M={A.shape[0]}: flag {int(flag)}/{io['convFlag']} iterations {info['iterations']}/{io['iterations']} refactor {info['numRefactor']}/{io['numRefactor']} "
+             f"max|x-x_oracle| {np.abs(x - xo).max():.2e}; setup {info['tSetup']*1e3:.1f} ms loop {info['tLoop']*1e3:.1f} ms call {(time.perf_counter()-t0)*1e3:.1f} ms")
+        assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+        assert np.abs(x - xo).max() <= ABS_DEV_THR
