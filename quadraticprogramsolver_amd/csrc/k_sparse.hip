@@ -510,6 +510,8 @@ template <typename T> struct SparseSolver : SolverBase {
             catch (const std::runtime_error& e) { throw QpsError(QPS_ERR_UNSUPPORTED, e.what()); }
             ldl = make_sparse_ldl<T>(st, std::move(sym), hPnz.data(), (int64_t)hPnz.size(), hAnz.data(), (int64_t)hAnz.size());
             ldl_valid = false;
+            for (auto* v : {&hPcp, &hPri, &hAcp, &hAri}) std::vector<int64_t>().swap(*v);           // the canonical host copies have served their purpose
+            std::vector<double>().swap(hPnz); std::vector<double>().swap(hAnz);
         }
         if (force || !ldl_valid || ldl_rho != rho || ldl_sigma != sigma) {
             ldl_valid = false;
