@@ -197,14 +197,15 @@ def run_dense(args, cfg, info, device, qps, qd, np, sync):
                                      "GBs": round(sw["algo_bytes"] / dur / 1e9, 1), "frac_of_8TBs": round(sw["algo_bytes"] / dur / 1e9 / HBM_PEAK_GBS, 4),
                                      "two_sweep_algo_bytes": s * (n * (n + 1) + 4 * n), "two_sweep_algo_GBs": round(s * (n * (n + 1) + 4 * n) / dur / 1e9, 1),
                                      "traffic": t_sw, "traffic_frac_of_8TBs": round(t_sw / dur / 1e9 / HBM_PEAK_GBS, 4) if t_sw else None, "traffic_source": src_sw}
-        if not args.no_time_to_eps and args.config == "c2":
-            # time-to-eps on the feasible variant (the plain m = 2n draw is primal infeasible: see generator docstring)
+        if not args.no_time_to_eps and args.config in ("c2", "c5"):
+            # time-to-eps on the feasible variant (the plain m = 2n draw is primal infeasible: see generator docstring); fp32 to 1e-4
             Pf, qf, Af, lf, uf = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank, feasible=True)
+            eps = 1e-6 if cfg["dtype"] == "f64" else 1e-4
             with qps.QuadraticProgram(Pf, qf, Af, lf, uf, dtype=cfg["dtype"], device=device) as pf:
                 xf = np.zeros(n); ti = {}
                 t1 = time.perf_counter()
-                flag = pf.solve(xf, numIterations=50000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True, trsvBlock=args.trsv_block, info=ti)
-                out["time_to_eps"] = {"eps": 1e-6, "rho0": 0.1, "adptRho": True, "flag": int(flag), "iterations": ti["iterations"],
+                flag = pf.solve(xf, numIterations=50000, ϵAbs=eps, ϵRel=eps, ρ=0.1, adptΡ=True, trsvBlock=args.trsv_block, info=ti)
+                out["time_to_eps"] = {"eps": eps, "rho0": 0.1, "adptRho": True, "flag": int(flag), "iterations": ti["iterations"],
                                       "refactorisations": ti["numRefactor"], "ms_total": round((time.perf_counter() - t1) * 1e3, 2),
                                       "ms_setup": round(ti["tSetup"] * 1e3, 2), "ms_loop": round(ti["tLoop"] * 1e3, 2),
                                       "problem": "randomQp density 1.0, bounds centred on A*x0 (feasible variant)"}
@@ -314,6 +315,17 @@ def run_batch(args, cfg, info, device, qps, qd, np, sync):
         out["kernels"] = kernel_list(ktimes)
         out["cpu_baseline"] = cpu_baseline_batch(first, cfg["batch"]) if (not args.no_cpu_baseline and info.world_size == 1) else None
     solver.close()
+    if info.rank == 0 and not args.no_time_to_eps:
+        # time-to-eps of this rank's slab on the feasible variant (every QP runs to its own stopping iteration, per-QP rho switches)
+        probs = [qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b, feasible=True) for b in range(begin, min(end, begin + 32))]
+        with qps.QuadraticProgramBatch(probs, dtype=cfg["dtype"], device=device) as sb:
+            t1 = time.perf_counter()
+            _, flags, infos2 = sb.solve(numIterations=50000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
+            out["time_to_eps"] = {"eps": 1e-6, "rho0": 0.1, "adptRho": True, "qps": len(probs), "ms_total": round((time.perf_counter() - t1) * 1e3, 2),
+                                  "ms_setup": round(infos2[0]["tSetup"] * 1e3, 2), "ms_loop": round(infos2[0]["tLoop"] * 1e3, 2),
+                                  "iterations_min_max": [min(i["iterations"] for i in infos2), max(i["iterations"] for i in infos2)],
+                                  "flags": sorted(set(int(f) for f in flags)), "refactorisations_max": max(i["numRefactor"] for i in infos2),
+                                  "problem": "randomQp density 1.0, bounds centred on A*x0 (feasible variant), first 32 QPs of rank 0's slab"}
     return out
 
 

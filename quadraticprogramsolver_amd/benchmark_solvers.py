@@ -17,11 +17,11 @@ import time
 
 import numpy as np
 
-from . import (ConvergenceFlag, GenerateRandomQP, HipCg, HipCgInit, HipChol, HipCholF32, HipCholF32Init, HipCholInit, ProblemClass,
+from . import (ConvergenceFlag, GenerateRandomQP, HipCg, HipCgInit, HipChol, HipCholF32, HipCholF32Init, HipCholInit, HipLdl, HipLdlInit, ProblemClass,
                QuadraticProgram, make_rng)
 
-SOLVERS = (("HipChol (dense Cholesky, fp64)", HipCholInit, HipChol), ("HipCholF32 (dense Cholesky, fp32)", HipCholF32Init, HipCholF32),
-           ("HipCg (CSR matrix-free CG, fp64)", HipCgInit, HipCg))
+SOLVERS = (("HipLdl (sparse KKT L D L', fp64)", HipLdlInit, HipLdl), ("HipChol (dense Cholesky, fp64)", HipCholInit, HipChol),
+           ("HipCholF32 (dense Cholesky, fp32)", HipCholF32Init, HipCholF32), ("HipCg (CSR matrix-free CG, fp64)", HipCgInit, HipCg))
 REF_KW = dict(numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=1, σ=1e-6, α=1.6, δ=1e-6, adptΡ=True, fctrΡ=5, numItrConv=25)   # BenchmarkSolvers.jl:48-57
 
 

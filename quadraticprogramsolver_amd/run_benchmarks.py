@@ -22,7 +22,9 @@ from . import _lib
 
 
 def run(csv_path: str, sizes=(2, 20), num_simulations: int = 5, samples: int = 15, num_iterations: int = 50000,
-        seed: int = 1234, linsys: str = "cholesky", device: int = 0):
+        seed: int = 1234, linsys: str = "ldl", device: int = 0):
+    """``linsys``: "ldl" = the sparse L D L' plugin, the counterpart of the FacLdlInit / FacLdl! pair RunBenchmarks.jl:54-55 selects
+    (default); "cholesky" = the dense reduced form; "cg" = matrix-free CG."""
     header = ["Solver Label", "Solver Version", "System Info", "Test Date Time"]       # RunBenchmarks.jl:79-82
     row = [f"QPS HIP {linsys}", _lib.lib().qps_version().decode(), "AMD Instinct MI355X (gfx950)",
            datetime.datetime.utcnow().strftime("%Y_%m_%d_%S_%M_%H")]                    # :61 date format kept
@@ -65,7 +67,7 @@ def main():
     ap.add_argument("--sizes", type=int, nargs="+", default=[2, 20])                    # :29-37 ([10 100] .÷ 5)
     ap.add_argument("--sims", type=int, default=5)                                      # :28
     ap.add_argument("--samples", type=int, default=15)                                  # :65
-    ap.add_argument("--linsys", default="cholesky", choices=["cholesky", "cg"])
+    ap.add_argument("--linsys", default="ldl", choices=["ldl", "cholesky", "cg"])        # :54-55 hLinSolInit = FacLdlInit
     a = ap.parse_args()
     header, row = run(a.csv, tuple(a.sizes), a.sims, a.samples, linsys=a.linsys)
     print(f"appended {len(row)} columns to {a.csv}")

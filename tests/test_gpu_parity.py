@@ -423,11 +423,11 @@ def test_benchmark_solvers_driver(gpu, tmp_path):
     assert bs.GenerateElementsVector(10, 1000, 3, logSpace=True) == [10, 100, 1000]
     f = str(tmp_path / "solvers.csv")
     vN, tR, rows = bs.run(20, 60, 0, 0, numDims=2, samples=2, csv_path=f)
-    assert vN == [20, 60] and tR.shape == (2, 3, 5) and len(rows) == 6
+    assert vN == [20, 60] and tR.shape == (2, 4, 5) and len(rows) == 8
     assert np.all(tR[:, :, 0] <= tR[:, :, 2]) and np.all(tR[:, :, 2] <= tR[:, :, 1]) and np.all(tR[:, :, 0] > 0)   # min <= median <= max
     assert np.all(tR[:, 0, 3] > 0)
     table = list(csv.reader(open(f)))
-    assert len(table) == 7 and table[0][0] == "Solver"
+    assert len(table) == 9 and table[0][0] == "Solver"
 
 
 def test_large_n_keeps_the_fused_kernels(gpu):
