@@ -96,6 +96,16 @@ __global__ __launch_bounds__(256) void k_ldl_densify(int e0, int e1, const int* 
     const int q = ent_q[e]; const T v = vc[q];
     Ld[ent_dst[e]] = v; Wd[ent_dst[e]] = v * D[cj[q]];
 }
+// Mt -= sum over the K-slices of one group of the partial products (fixed order: bitwise reproducible), lower tiles only
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_sub_slabs(int ldt, int nslab, const T* __restrict__ slabs, T* __restrict__ Mt) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= ldt || j > (i | 63)) return;
+    const int64_t e = (int64_t)i * ldt + j, tt = (int64_t)ldt * ldt;
+    T s = T(0);
+    for (int c = 0; c < nslab; ++c) s += slabs[(int64_t)c * tt + e];
+    Mt[e] -= s;
+}
 // u <- J u between the two sweeps of a tail with constraint rows in it (K_tt = Lt J Lt': x = inv(Lt)' J inv(Lt) t).  The signs
 // cannot live in the sweep matrix: its diagonal is shared by the lower (forward) and the upper (backward) triangle.
 template <typename T>
@@ -134,8 +144,17 @@ __global__ __launch_bounds__(256) void k_ldl_fwd(int r0, int r1, int Ns, const i
     const int r = r0 + g;
     const bool valid = r < r1;
     T s = T(0);
-    if (valid)
-        for (int k = rp[r] + lane; k < rp[r + 1]; k += LPR) s += vr[k] * b[ci[k]];
+    if (valid) {
+        // four independent gathers in flight per lane (a single accumulator makes every load wait for the previous add); the partial sums
+        // are added in a fixed order
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+        int k = rp[r] + lane; const int ke = rp[r + 1];
+        for (; k + 3 * LPR < ke; k += 4 * LPR) {
+            s0 += vr[k] * b[ci[k]]; s1 += vr[k + LPR] * b[ci[k + LPR]]; s2 += vr[k + 2 * LPR] * b[ci[k + 2 * LPR]]; s3 += vr[k + 3 * LPR] * b[ci[k + 3 * LPR]];
+        }
+        for (; k < ke; k += LPR) s0 += vr[k] * b[ci[k]];
+        s = (s0 + s1) + (s2 + s3);
+    }
     s = group_sum<T, LPR>(s);
     if (valid && lane == LPR - 1) { const T v = b[r] - s; if (r >= Ns) tb[r - Ns] = v; else b[r] = v; }
 }
@@ -147,8 +166,14 @@ __global__ __launch_bounds__(256) void k_ldl_bwd(int c0, int c1, int Ns, const i
     const int j = c0 + g;
     const bool valid = j < c1;
     T s = T(0);
-    if (valid)
-        for (int q = cp[j] + lane; q < cp[j + 1]; q += LPR) { const int i = ri[q]; s += vc[q] * (i >= Ns ? tx[i - Ns] : b[i]); }
+    if (valid) {
+        T s0 = T(0), s1 = T(0);
+        auto xv = [&](int i) { return i >= Ns ? tx[i - Ns] : b[i]; };
+        int q = cp[j] + lane; const int qe = cp[j + 1];
+        for (; q + LPR < qe; q += 2 * LPR) { s0 += vc[q] * xv(ri[q]); s1 += vc[q + LPR] * xv(ri[q + LPR]); }
+        for (; q < qe; q += LPR) s0 += vc[q] * xv(ri[q]);
+        s = s0 + s1;
+    }
     s = group_sum<T, LPR>(s);
     if (valid && lane == LPR - 1) b[j] = b[j] * Dinv[j] - s;
 }
@@ -275,7 +300,8 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
     DevVec<int64_t> kdst; DevVec<signed char> sign;
     DevVec<T> kval, vr, vc, D0, D, Dinv, b, tb, tu, tx, tsgn, Mt, St, tmp, dinv, Ld, Wd;
     DevVec<int> fail;
-    std::vector<int> chunk_ptr; int KC = 16, nb = 64; bool tail_signed = false;
+    std::vector<int> group_ptr; int KC = 16, GS = 1, nb = 64; bool tail_signed = false;   // Schur complement: groups of GS K-slices of KC columns
+    DevVec<T> slabs;
     std::vector<int> lpr_fwd, lpr_bwd; int lpr_tail = 1;
 
     SparseLdlImpl(hipStream_t st_, LdlSymbolic&& sym, const double* Pv, int64_t pnnz, const double* Av, int64_t annz) : st(st_), S(std::move(sym)) {
@@ -312,18 +338,26 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
                 const int* it = std::lower_bound(lo, hi, Ns);
                 if (it != hi) { tcol_first[j] = (int)(it - S.ri.data()); ++ntc; }
             }
-            const int kc_cap = std::max(16, (int)std::min<int64_t>(4096, ((int64_t)1 << 26) / std::max(ldt, 1) / 16 * 16));   // two panels of ldt x KC stay below 1 GiB
-            KC = std::min(kc_cap, std::max(16, (ntc + 15) / 16 * 16));
-            std::vector<int> eq, ed; chunk_ptr.assign(1, 0);
-            int kk = 0;
+            // Schur complement of the tail on the MFMA GEMM, split along K: the tail has few 64 x 64 tiles (3 at ldt = 128) and tens of thousands
+            // of columns to sum over, so K is cut into slices of KC columns that run as ONE batched launch (blockIdx.z = slice) into per-slice
+            // slabs, which k_ldl_sub_slabs subtracts in fixed order; a group = the slices that fit a 1 GiB budget (usually all of them)
+            const int64_t tiles = (int64_t)(ldt / 64) * (ldt / 64 + 1) / 2;
+            int nsplit = (int)std::min<int64_t>(256, std::max<int64_t>(1, 768 / tiles));
+            KC = std::max(64, ((ntc + nsplit - 1) / nsplit + 15) / 16 * 16);
+            KC = std::min(KC, 4096);
+            nsplit = std::max(1, (ntc + KC - 1) / KC);
+            const int64_t budget = ((int64_t)1 << 30) / (int64_t)sizeof(T);                      // elements
+            GS = (int)std::max<int64_t>(1, std::min<int64_t>(nsplit, budget / ((int64_t)2 * ldt * KC + (int64_t)ldt * ldt)));
+            std::vector<int> eq, ed; group_ptr.assign(1, 0);
+            int kk = 0;                                                                        // column index inside the current group
             for (int j = 0; j < Ns; ++j) {
                 if (tcol_first[j] < 0) continue;
-                for (int q = tcol_first[j]; q < S.cp[j + 1]; ++q) { eq.push_back(q); ed.push_back((S.ri[q] - Ns) * KC + kk); }
-                if (++kk == KC) { chunk_ptr.push_back((int)eq.size()); kk = 0; }
+                for (int q = tcol_first[j]; q < S.cp[j + 1]; ++q) { eq.push_back(q); ed.push_back((S.ri[q] - Ns) * (GS * KC) + kk); }
+                if (++kk == GS * KC) { group_ptr.push_back((int)eq.size()); kk = 0; }
             }
-            if (kk > 0) chunk_ptr.push_back((int)eq.size());
+            if (kk > 0) group_ptr.push_back((int)eq.size());
             ent_q.upload(eq, up); ent_dst.upload(ed, up);
-            if (chunk_ptr.size() > 1) { Ld.alloc((int64_t)ldt * KC, st); Wd.alloc((int64_t)ldt * KC, st); }
+            if (group_ptr.size() > 1) { Ld.alloc((int64_t)ldt * GS * KC, st); Wd.alloc((int64_t)ldt * GS * KC, st); slabs.alloc((int64_t)GS * ldt * ldt, st); }
         }
         const int L = (int)S.level_ptr.size() - 1;
         lpr_fwd.assign(std::max(L, 0), 1); lpr_bwd.assign(std::max(L, 0), 1);
@@ -359,12 +393,14 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
                                             csc2csr.p, D.p, Dinv.p, vr.p, vc.p);
         }
         if (ldt > 0) {
-            for (size_t c = 0; c + 1 < chunk_ptr.size(); ++c) {                     // Mt -= (L_ts D) L_ts' chunk by chunk (lower tiles)
-                const int e0 = chunk_ptr[c], e1 = chunk_ptr[c + 1];
-                HIPC(hipMemsetAsync(Ld.p, 0, sizeof(T) * (size_t)ldt * KC, st));
-                HIPC(hipMemsetAsync(Wd.p, 0, sizeof(T) * (size_t)ldt * KC, st));
+            for (size_t gI = 0; gI + 1 < group_ptr.size(); ++gI) {                  // Mt -= (L_ts D) L_ts', group by group (lower tiles)
+                const int e0 = group_ptr[gI], e1 = group_ptr[gI + 1];
+                const int64_t Kg = (int64_t)GS * KC;
+                HIPC(hipMemsetAsync(Ld.p, 0, sizeof(T) * (size_t)ldt * Kg, st));
+                HIPC(hipMemsetAsync(Wd.p, 0, sizeof(T) * (size_t)ldt * Kg, st));
                 hipLaunchKernelGGL((k_ldl_densify<T>), dim3((e1 - e0 + 255) / 256), dim3(256), 0, st, e0, e1, ent_q.p, ent_dst.p, cj.p, vc.p, D.p, Ld.p, Wd.p);
-                gemm<T>(st, ldt, ldt, KC, T(-1), Wd.p, KC, true, Ld.p, KC, true, T(1), Mt.p, ldt, true);
+                gemm<T>(st, ldt, ldt, KC, T(1), Wd.p, Kg, true, Ld.p, Kg, true, T(0), slabs.p, ldt, true, GS, KC, KC, (int64_t)ldt * ldt);
+                hipLaunchKernelGGL((k_ldl_sub_slabs<T>), dim3((ldt + 255) / 256, ldt), dim3(256), 0, st, ldt, GS, slabs.p, Mt.p);
             }
             if (tail_signed) cholesky_signed<T>(st, ldt, Mt.p, dinv.p, fail.p + 1, tsgn.p, tmp.p);
             else cholesky<T>(st, ldt, Mt.p, dinv.p, fail.p + 1);
