@@ -403,7 +403,7 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
                 hipLaunchKernelGGL((k_ldl_sub_slabs<T>), dim3((ldt + 255) / 256, ldt), dim3(256), 0, st, ldt, GS, slabs.p, Mt.p);
             }
             if (tail_signed) cholesky_signed<T>(st, ldt, Mt.p, dinv.p, fail.p + 1, tsgn.p, tmp.p);
-            else cholesky<T>(st, ldt, Mt.p, dinv.p, fail.p + 1);
+            else cholesky<T>(st, ldt, Mt.p, dinv.p, fail.p + 1, 1, chol_scratch_fits(ldt) ? St.p : nullptr);
             build_sweep_matrix<T>(st, ldt, nb, Mt.p, dinv.p, St.p, tmp.p);
         }
         int f[2] = {0, 0};

@@ -29,6 +29,7 @@ template <> struct Mfma<float> {
 constexpr int GT = 64;    // C tile edge per workgroup
 constexpr int GK = 16;    // K depth per LDS stage
 constexpr int GLD = 80;   // LDS row stride (elements): k-groups of a fragment read land 32 banks apart
+constexpr int LPS = 20;   // row stride of the published 64 x 16 Cholesky panel: rows 16-byte aligned (b128 LDS reads in the rank-16 update)
 
 // 64 x 64 C tile per 256-thread workgroup; waves in a 2 x 2 grid, each wave 2 x 2 MFMA 16 x 16 tiles.
 // tile != nullptr: the finished C tile goes to that LDS array (row stride 65) INSTEAD of global memory
@@ -181,14 +182,24 @@ __device__ __forceinline__ float rsqrt_nr(float d) {
     return y;
 }
 
+// phase clock of the step kernel for tests/tools/micro/chol_chain.hip (compiled out of the library)
+#ifdef QPS_CHOL_TIMING
+__device__ long long g_chol_clock[16];
+__device__ long long g_potrf_clock[16];
+#define CHOL_T(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_clock[k] = wall_clock64(); } while (0)
+#define POTRF_T(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_potrf_clock[k] = wall_clock64(); } while (0)
+#else
+#define CHOL_T(k) do { } while (0)
+#define POTRF_T(k) do { } while (0)
+#endif
 template <typename T, int P, int K> struct PotrfCol {
-    static __device__ __forceinline__ void run(T (&a)[16], int i, int kb, int* fail) {
+    static __device__ __forceinline__ void run(T (&a)[16], int i, int col0, int* fail) {
         T d = lane_bcast<16 * P + K>(a[K]);
-        if (!(d > T(0))) { if (i == 0) atomicCAS(fail, 0, kb * 64 + 16 * P + K + 1); d = T(1); }
+        if (!(d > T(0))) { if (i == 0 && fail) atomicCAS(fail, 0, col0 + 16 * P + K + 1); d = T(1); }
         const T rs = rsqrt_nr(d);
         a[K] *= rs;                                          // l_ik for i >= k (row k itself: d * rs = sqrt(d))
         PotrfCol<T, P, K>::template update<K + 1>(a);
-        PotrfCol<T, P, K + 1>::run(a, i, kb, fail);
+        PotrfCol<T, P, K + 1>::run(a, i, col0, fail);
     }
     template <int J> static __device__ __forceinline__ void update(T (&a)[16]) {
         if constexpr (J < 16) {
@@ -201,23 +212,41 @@ template <typename T, int P, int K> struct PotrfCol {
 template <typename T, int P> struct PotrfCol<T, P, 16> { static __device__ __forceinline__ void run(T (&)[16], int, int, int*) {} };
 
 template <typename T, int P>
-__device__ __forceinline__ void potrf_panel(T (&a)[16], T (*Lp)[17], int i, int g, int kb, int* fail) {
+__device__ __forceinline__ void potrf_panel(T (&a)[16], T (*Lp)[LPS], int i, int g, int col0, int* fail) {
     if (g == P) {                                            // wave-uniform
-        PotrfCol<T, P, 0>::run(a, i, kb, fail);
+        POTRF_T(3 * P);
+        PotrfCol<T, P, 0>::run(a, i, col0, fail);
+        POTRF_T(3 * P + 1);
 #pragma unroll
         for (int k = 0; k < 16; ++k) Lp[i][k] = a[k];
     }
     __syncthreads();
+    if (g == 3) POTRF_T(3 * P + 2);
     if (g > P) {
         T li[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) li[k] = Lp[i][k];
+        if constexpr (sizeof(T) == 4) {
+            // v_mfma_f32_4x4x1 (16 blocks of 4 x 4, one per 4 lanes): lane 4b + n receives D_b[m][n] = sum_k A_b[m][k] B_b[k][n] in register m,
+            // A_b[m][k] supplied by lane 4b + m, B_b[k][n] by lane 4b + n.  With B = this lane's own panel row and A = panel row 16g + 4q + m,
+            // lane i ends up with the corrections of its own a[4q .. 4q+3]: the lane = row layout of the factorisation is kept.
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            T s = T(0);
+            for (int q = 0; q < 4; ++q) {
+                const T* ar = &Lp[16 * g + 4 * q + (i & 3)][0];
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += li[k] * Lp[16 * g + jj][k];   // same address for all lanes: broadcast
-            a[jj] -= s;
+                for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[k], li[k], acc, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[4 * q + m] -= acc[m];
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s += li[k] * Lp[16 * g + jj][k];   // same address for all lanes: broadcast
+                a[jj] -= s;
+            }
         }
     }
     __syncthreads();
@@ -226,15 +255,15 @@ __device__ __forceinline__ void potrf_panel(T (&a)[16], T (*Lp)[17], int i, int 
 // src: the block to factorise, either in place in global memory (src == nullptr) or in an LDS tile (row stride 65)
 template <typename T>
 __device__ __forceinline__ void potrf_block(T* __restrict__ blk, int64_t ld, int kb, int* __restrict__ fail, T (*src)[65]) {
-    __shared__ T Lp[64][17];
+    __shared__ __attribute__((aligned(16))) T Lp[64][LPS];
     const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
     T a[16];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) a[jj] = src ? src[i][16 * g + jj] : blk[(int64_t)i * ld + 16 * g + jj];
-    potrf_panel<T, 0>(a, Lp, i, g, kb, fail);
-    potrf_panel<T, 1>(a, Lp, i, g, kb, fail);
-    potrf_panel<T, 2>(a, Lp, i, g, kb, fail);
-    potrf_panel<T, 3>(a, Lp, i, g, kb, fail);
+    potrf_panel<T, 0>(a, Lp, i, g, kb * 64, fail);
+    potrf_panel<T, 1>(a, Lp, i, g, kb * 64, fail);
+    potrf_panel<T, 2>(a, Lp, i, g, kb * 64, fail);
+    potrf_panel<T, 3>(a, Lp, i, g, kb * 64, fail);
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const int j = 16 * g + jj;
@@ -265,6 +294,241 @@ __global__ __launch_bounds__(256) void k_update_potrf(T* __restrict__ M, int64_t
         __syncthreads();
         potrf_block<T>(A22, ld, kb + 1, fail, tile);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 128-column steps: ONE panel launch + ONE plain GEMM launch per 128 columns (the 64-column chain above costs two launches per 64).
+// Every workgroup of the panel launch factorises the 128 x 128 diagonal block of the step by itself, in LDS (redundantly: no
+// hand-off between workgroups), inverts the factor (W = inv(L), recursive doubling on the MFMA pipe) and forms its own 64 rows of
+// the panel as the product L21 = A21 W' instead of a 64-step substitution.  Workgroup 0 publishes the factor of the diagonal
+// block (to `stash`, because the other workgroups may still be reading the unfactorised block from M) and the inverses of the
+// two 64 x 64 diagonal blocks (dinv).
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row stride of the LDS tiles of the step kernel: the MFMA fragment reads of mm64 (16 rows x 4 consecutive k per wave) are free of bank
+// conflicts when the stride is 4 mod 64 words (fp32: 68) resp. 2 mod 32 double words (fp64: 66)
+template <typename T> struct TS { static constexpr int v = sizeof(T) == 4 ? 68 : 66; };
+template <typename T> struct LV {   // view of a sub-block of an LDS tile: element (i, j) at p[i * rs + j * cs]
+    T* p; int rs, cs;
+    __device__ __forceinline__ T& at(int i, int j) const { return p[i * rs + j * cs]; }
+};
+template <typename T> __device__ __forceinline__ LV<T> lv(T (*t)[TS<T>::v], int r0 = 0, int c0 = 0) { return LV<T>{&t[r0][c0], TS<T>::v, 1}; }
+template <typename T> __device__ __forceinline__ LV<T> lvT(T (*t)[TS<T>::v], int r0 = 0, int c0 = 0) { return LV<T>{&t[r0][c0], 1, TS<T>::v}; }   // (i, j) -> t[r0 + j][c0 + i]
+
+// 64 x 64 product held in registers: waves in a 2 x 2 grid, each wave the row tiles {wm, 3 - wm} and the column tiles {wn, 3 - wn}
+// (16 x 16 MFMA tiles; the interleaving balances the waves when a triangular operand lets a product skip part of the depth)
+template <typename T> struct Acc64 {
+    typename Mfma<T>::acc_t v[2][2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[a][b][r] = T(0);
+    }
+    static __device__ __forceinline__ int tile_of(int w, int a) { return a == 0 ? w : 3 - w; }
+    // f(row, col, value) for the 16 entries this lane holds
+    template <typename F> __device__ __forceinline__ void foreach(F&& f) const {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f(tile_of(wm, a) * 16 + Mfma<T>::row(lane, r), tile_of(wn, b) * 16 + (lane & 15), v[a][b][r]);
+    }
+};
+// c += A * B, all 64 x 64, operands in LDS.  TRI 1: B(k, j) = 0 for k > j (the transpose of a lower-triangular tile): the depth of a
+// column tile stops at its last column
+template <typename T, int TRI = 0> __device__ __forceinline__ void mm64(Acc64<T>& c, LV<T> A, LV<T> B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int cl = lane & 15, kq = lane >> 4;
+    const int r0 = wm * 16 + cl, r1 = (3 - wm) * 16 + cl, c0 = wn * 16 + cl, c1 = (3 - wn) * 16 + cl;
+    const int kend0 = TRI == 1 ? (wn + 1) * 16 : 64;                               // column tile wn <= column tile 3 - wn
+#pragma unroll 8
+    for (int kk = 0; kk < kend0; kk += 4) {
+        const int kr = kk + kq;
+        const T a0 = A.at(r0, kr), a1 = A.at(r1, kr);
+        const T b0 = B.at(kr, c0), b1 = B.at(kr, c1);
+        c.v[0][0] = Mfma<T>::run(a0, b0, c.v[0][0]);
+        c.v[0][1] = Mfma<T>::run(a0, b1, c.v[0][1]);
+        c.v[1][0] = Mfma<T>::run(a1, b0, c.v[1][0]);
+        c.v[1][1] = Mfma<T>::run(a1, b1, c.v[1][1]);
+    }
+    if (TRI == 1) {
+        const int kend1 = (4 - wn) * 16;
+#pragma unroll 4
+        for (int kk = kend0; kk < kend1; kk += 4) {
+            const int kr = kk + kq;
+            const T a0 = A.at(r0, kr), a1 = A.at(r1, kr);
+            const T b1 = B.at(kr, c1);
+            c.v[0][1] = Mfma<T>::run(a0, b1, c.v[0][1]);
+            c.v[1][1] = Mfma<T>::run(a1, b1, c.v[1][1]);
+        }
+    }
+}
+// D = alpha * A * B for an MS x NS x KS sub-block product (multiples of 16), 16 x 16 output tiles dealt to the four waves; D must not
+// alias A or B
+template <typename T> __device__ __forceinline__ void mm_sub(int MS, int NS, int KS, T alpha, LV<T> A, LV<T> B, LV<T> D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 15, kq = lane >> 4;
+    const int tn = NS >> 4, tiles = (MS >> 4) * tn;
+    for (int t = wave; t < tiles; t += 4) {
+        const int ti = t / tn, tj = t - ti * tn;
+        typename Mfma<T>::acc_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = T(0);
+        for (int k0 = 0; k0 < KS; k0 += 4) acc = Mfma<T>::run(A.at(ti * 16 + cl, k0 + kq), B.at(k0 + kq, tj * 16 + cl), acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D.at(ti * 16 + Mfma<T>::row(lane, r), tj * 16 + cl) = alpha * acc[r];
+    }
+}
+
+template <typename T, int I> struct TriInv16 {
+    // row I of the inverse of a 16 x 16 lower-triangular block, one column per lane: x_I = (e_I - sum_{p<I} L[I][p] x_p) / L[I][I]
+    static __device__ __forceinline__ void run(T (&x)[16], const T (*X)[TS<T>::v], int o, int j, T rd) {
+        T s = (j == I) ? T(1) : T(0);
+#pragma unroll
+        for (int p = 0; p < I; ++p) s -= X[o + I][o + p] * x[p];          // same address in every lane: LDS broadcast
+        x[I] = s * lane_bcast<I>(rd);
+        TriInv16<T, I + 1>::run(x, X, o, j, rd);
+    }
+};
+template <typename T> struct TriInv16<T, 16> { static __device__ __forceinline__ void run(T (&)[16], const T (*)[TS<T>::v], int, int, T) {} };
+
+// X (64 x 64 lower triangular, upper part zero) <- inv(X) in place; Y: scratch tile.  Ends with a barrier.
+template <typename T> __device__ __forceinline__ void tri_inv64(T (*X)[TS<T>::v], T (*Y)[TS<T>::v]) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (g == 0) POTRF_T(12);
+    {   // the four 16 x 16 diagonal blocks, one per wave
+        const int o = 16 * g, j = lane & 15;
+        const T rd = T(1) / X[o + j][o + j];
+        T x[16];
+        TriInv16<T, 0>::run(x, X, o, j, rd);
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) X[o + i][o + j] = x[i];
+        }
+    }
+    __syncthreads();
+    if (g == 0) POTRF_T(13);
+    // inv([L00 0; L10 L11]) = [W00 0; -W11 L10 W00, W11]: 16 -> 32 (two pairs), 32 -> 64
+    for (int p = 0; p < 2; ++p) mm_sub<T>(16, 16, 16, T(1), lv(X, 32 * p + 16, 32 * p), lv(X, 32 * p, 32 * p), lv(Y, 32 * p + 16, 32 * p));
+    __syncthreads();
+    for (int p = 0; p < 2; ++p) mm_sub<T>(16, 16, 16, T(-1), lv(X, 32 * p + 16, 32 * p + 16), lv(Y, 32 * p + 16, 32 * p), lv(X, 32 * p + 16, 32 * p));
+    __syncthreads();
+    if (g == 0) POTRF_T(14);
+    mm_sub<T>(32, 32, 32, T(1), lv(X, 32, 0), lv(X, 0, 0), lv(Y, 32, 0));
+    __syncthreads();
+    mm_sub<T>(32, 32, 32, T(-1), lv(X, 32, 32), lv(Y, 32, 0), lv(X, 32, 0));
+    __syncthreads();
+    if (g == 0) POTRF_T(15);
+}
+
+// Cholesky factor of the 64 x 64 tile in LDS, in place (upper part zeroed).  Ends with a barrier.
+template <typename T> __device__ __forceinline__ void potrf_tile(T (*tile)[TS<T>::v], T (*Lp)[LPS], int col0, int* fail) {
+    const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    T a[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) a[jj] = tile[i][16 * g + jj];
+    potrf_panel<T, 0>(a, Lp, i, g, col0, fail);
+    potrf_panel<T, 1>(a, Lp, i, g, col0, fail);
+    potrf_panel<T, 2>(a, Lp, i, g, col0, fail);
+    potrf_panel<T, 3>(a, Lp, i, g, col0, fail);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { const int j = 16 * g + jj; tile[i][j] = (j <= i) ? a[jj] : T(0); }
+    __syncthreads();
+}
+template <typename T> __device__ __forceinline__ void tile_load(T (*tile)[TS<T>::v], const T* __restrict__ src, int64_t ld) {
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int r = g + 4 * i; tile[r][c] = src[(int64_t)r * ld + c]; }
+}
+template <typename T> __device__ __forceinline__ void tile_store(T* __restrict__ dst, int64_t ld, const T (*tile)[TS<T>::v]) {
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int r = g + 4 * i; dst[(int64_t)r * ld + c] = tile[r][c]; }
+}
+
+// One step of the factorisation: columns [64 cb, 64 (cb + w)), w = 1 or 2 blocks (w = 1 only for a last odd block: nrb = 0 then).
+// grid (max(nrb, 1), batch); workgroup b < nrb owns rows 64 (cb + w + b) .. + 63 of the panel.
+// stash: 3 tiles (L00, L10, L11; row-major 64 x 64 each) per step and matrix.
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_step(T* __restrict__ M, int64_t ld, int cb, int w, int nrb, T* __restrict__ dinv, T* __restrict__ stash,
+                                                   int* __restrict__ fail, int64_t sM, int64_t sD, int64_t sS) {
+    __shared__ T B0[64][TS<T>::v];
+    __shared__ T B1[64][TS<T>::v];
+    __shared__ T B2[64][TS<T>::v];
+    __shared__ T B3[64][TS<T>::v];
+    __shared__ __attribute__((aligned(16))) T Lp[64][LPS];
+    M += (int64_t)blockIdx.y * sM; dinv += (int64_t)blockIdx.y * sD; stash += (int64_t)blockIdx.y * sS + (int64_t)(cb >> 1) * 3 * 4096;
+    const bool lead = blockIdx.x == 0;                                             // workgroup-uniform
+    int* myfail = lead ? fail + blockIdx.y : nullptr;
+    const int c0 = cb * 64;
+    const T* D = M + (int64_t)c0 * ld + c0;
+    tile_load<T>(B0, D, ld);
+    if (w == 2) { tile_load<T>(B1, D + 64 * ld, ld); tile_load<T>(B2, D + 64 * ld + 64, ld); }
+    __syncthreads();
+    CHOL_T(0);
+    potrf_tile<T>(B0, Lp, c0, myfail);
+    CHOL_T(1);
+    if (lead) tile_store<T>(stash, 64, B0);                                        // L00
+    tri_inv64<T>(B0, B3);                                                          // B0 = W00
+    CHOL_T(2);
+    if (lead) tile_store<T>(dinv + (int64_t)cb * 4096, 64, B0);
+    if (w == 2) {
+        Acc64<T> c;
+        c.zero(); mm64<T, 1>(c, lv(B1), lvT(B0));                                  // L10 = D10 W00'
+        __syncthreads();
+        c.foreach([&](int r, int cc, T v) { B1[r][cc] = v; });
+        __syncthreads();
+        if (lead) tile_store<T>(stash + 4096, 64, B1);
+        CHOL_T(3);
+        c.zero(); mm64<T>(c, lv(B1), lvT(B1));                                     // D11 -= L10 L10'
+        c.foreach([&](int r, int cc, T v) { B2[r][cc] -= v; });
+        __syncthreads();
+        CHOL_T(4);
+        potrf_tile<T>(B2, Lp, c0 + 64, myfail);
+        CHOL_T(5);
+        if (lead) tile_store<T>(stash + 8192, 64, B2);                             // L11
+        tri_inv64<T>(B2, B3);                                                      // B2 = W11
+        CHOL_T(6);
+        if (lead) tile_store<T>(dinv + (int64_t)(cb + 1) * 4096, 64, B2);
+        CHOL_T(7);
+    }
+    if ((int)blockIdx.x < nrb) {
+        // this workgroup's 64 rows of L21 = A21 inv(L11)' with inv(L) = [W00 0; -W11 L10 W00, W11]:
+        //   X0 = A0 W00',  X1 = (A1 - X0 L10') W11'      (the off-diagonal block of the inverse is never formed)
+        T* Ab = M + (int64_t)(c0 + w * 64 + blockIdx.x * 64) * ld + c0;
+        tile_load<T>(B3, Ab, ld);
+        __syncthreads();
+        Acc64<T> x0, x1;
+        x0.zero(); mm64<T, 1>(x0, lv(B3), lvT(B0));
+        __syncthreads();                                                           // every wave is done with A0 (B3) and W00 (B0)
+        x0.foreach([&](int r, int cc, T v) { B3[r][cc] = v; });                    // X0 becomes an operand
+        tile_load<T>(B0, Ab + 64, ld);                                             // A1
+        __syncthreads();
+        x1.zero(); mm64<T>(x1, lv(B3), lvT(B1));                                   // X0 L10'
+        __syncthreads();
+        x1.foreach([&](int r, int cc, T v) { B3[r][cc] = B0[r][cc] - v; });        // T = A1 - X0 L10'
+        __syncthreads();
+        x1.zero(); mm64<T, 1>(x1, lv(B3), lvT(B2));
+        x0.foreach([&](int r, int cc, T v) { Ab[(int64_t)r * ld + cc] = v; });
+        x1.foreach([&](int r, int cc, T v) { Ab[(int64_t)r * ld + 64 + cc] = v; });
+        CHOL_T(8);
+    }
+}
+// the factors of the diagonal blocks, stashed by the step kernels, go to their place in M
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_unstash(T* __restrict__ M, int64_t ld, const T* __restrict__ stash, int nblk, int64_t sM, int64_t sS) {
+    const int step = blockIdx.x, which = blockIdx.y;                               // which: 0 = L00, 1 = L10, 2 = L11
+    const int cb = 2 * step;
+    if (which > 0 && cb + 1 >= nblk) return;
+    M += (int64_t)blockIdx.z * sM; stash += (int64_t)blockIdx.z * sS;
+    const T* src = stash + ((int64_t)step * 3 + which) * 4096;
+    T* dst = M + (int64_t)(cb + (which > 0)) * 64 * ld + (cb + (which == 2)) * 64;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int r = g + 4 * i; dst[(int64_t)r * ld + c] = src[r * 64 + c]; }
 }
 
 // Inverses of ALL 64 x 64 diagonal blocks of L in one launch (blockIdx.x = block): forward elimination on the identity,
@@ -406,10 +670,32 @@ template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const
 
 // batch > 1: the same factorisation for `batch` matrices NP*NP apart (dinv blocks (NP/64)*4096 apart, fail flags 1 apart):
 // every launch carries all QPs, so the launch-latency-bound panel chain is paid once instead of `batch` times.
-template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch) {
+// scratch (optional, NP * 96 elements per matrix, batch * NP * NP apart... see chol_scratch_elems): selects the 128-column steps.
+static int chol_step_width() {
+    static const int w = [] { const char* e = getenv("QPS_CHOL_STEP"); return (e && atoi(e) == 64) ? 64 : 128; }();
+    return w;
+}
+template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch, T* scratch) {
     (void)hipMemsetAsync(fail_dev, 0, sizeof(int) * batch, st);
     const int nblk = NP / 64;
     const int64_t sM = (int64_t)NP * NP, sD = (int64_t)nblk * 4096;
+    if (scratch && chol_step_width() == 128) {
+        const int64_t sS = chol_scratch_elems(NP);
+        for (int cb = 0; cb < nblk; cb += 2) {
+            const int w = (nblk - cb >= 2) ? 2 : 1;
+            const int rem = NP - (cb + w) * 64;
+            // diagonal block (every workgroup, redundantly) + panel L21 = A21 inv(L11)' (64 rows per workgroup)
+            hipLaunchKernelGGL((k_chol_step<T>), dim3(rem > 0 ? rem / 64 : 1, batch), dim3(256), 0, st, M, (int64_t)NP, cb, w, rem / 64, dinv, scratch,
+                               fail_dev, sM, sD, sS);
+            if (rem > 0) {   // A22 -= L21 L21' (lower tiles), depth 128
+                const T* A21 = M + (int64_t)(cb + w) * 64 * NP + cb * 64;
+                T* A22 = M + (int64_t)(cb + w) * 64 * NP + (cb + w) * 64;
+                gemm<T>(st, rem, rem, w * 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true, batch, sM, sM, sM, 0);
+            }
+        }
+        hipLaunchKernelGGL((k_chol_unstash<T>), dim3((nblk + 1) / 2, 3, batch), dim3(256), 0, st, M, (int64_t)NP, scratch, nblk, sM, sS);
+        return;
+    }
     hipLaunchKernelGGL((k_potrf64<T>), dim3(batch), dim3(256), 0, st, M, (int64_t)NP, 0, fail_dev, sM);
     for (int kb = 0; kb < nblk; ++kb) {
         const int rem = NP - (kb + 1) * 64;
@@ -461,7 +747,7 @@ template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, co
                           bool, int, int64_t, int64_t, int64_t, int);                                                  \
     template void make_PI<T>(hipStream_t, int, int, const T*, T, T*, int);                                             \
     template void assemble_M<T>(hipStream_t, int, const T*, const T*, T, T*, int, const double*);                      \
-    template void cholesky<T>(hipStream_t, int, T*, T*, int*, int);                                                    \
+    template void cholesky<T>(hipStream_t, int, T*, T*, int*, int, T*);                                                    \
     template void build_sweep_matrix<T>(hipStream_t, int, int, const T*, const T*, T*, T*, int);
 INST(double)
 INST(float)

@@ -218,7 +218,7 @@ template <typename T> struct DenseSolver : SolverBase {
             have_AA = true;
         }
         assemble_M<T>(st, NP, PI, AA, (T)rho, M);                                                    // :114 / :128
-        cholesky<T>(st, NP, M, dinv, fail);
+        cholesky<T>(st, NP, M, dinv, fail, 1, chol_scratch_fits(NP) ? S : nullptr);   // S is rebuilt right after: free as scratch
         build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp);
         int f = 0;
         HIPC(hipMemcpyAsync(&f, fail, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -566,7 +566,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         }
         assemble_M<T>(st, NP, PIb, AAb, (T)rho, Mb);
         T* dinvb = dinv + (int64_t)b * (NP / 64) * 4096;
-        cholesky<T>(st, NP, Mb, dinvb, fail + b);
+        cholesky<T>(st, NP, Mb, dinvb, fail + b, 1, chol_scratch_fits(NP) ? Sb : nullptr);
         build_sweep_matrix<T>(st, NP, nb, Mb, dinvb, Sb, tmp + b * nn);
     }
     // all QPs at once (same rho): every launch of the panel chain carries the whole batch
@@ -577,7 +577,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
             gemm<T>(st, NP, NP, MP, T(1), A, NP, false, A, NP, false, T(0), AA, NP, true, count, (int64_t)MP * NP, (int64_t)MP * NP, nn);
         }
         assemble_M<T>(st, NP, PI, AA, (T)rho, M, count, rho_arr);
-        cholesky<T>(st, NP, M, dinv, fail, count);
+        cholesky<T>(st, NP, M, dinv, fail, count, chol_scratch_fits(NP) ? S : nullptr);
         build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp, count);
     }
     void check_fail(const std::vector<int>& which) {

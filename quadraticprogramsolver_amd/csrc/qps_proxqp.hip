@@ -184,7 +184,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         }
         make_PI<T>(st, (int)n, NP, P, (T)sigma, PI);
         assemble_M<T>(st, NP, PI, KK, (T)rho, M);                                                   // :178-180
-        cholesky<T>(st, NP, M, dinv, fail);                                                         // :196
+        cholesky<T>(st, NP, M, dinv, fail, 1, chol_scratch_fits(NP) ? S : nullptr);                 // :196
         nb = pick(NP);
         build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp);
         check_fail("P + rho (A'A + C'C) + sigma I");
@@ -210,7 +210,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         const int nbP = pick(NP);
         make_PI<T>(st, (int)n, NP, P, T(0), PI);                     // P with identity on the padding
         HIPC(hipMemcpyAsync(M, PI, sizeof(T) * (size_t)NP * NP, hipMemcpyDeviceToDevice, st));
-        cholesky<T>(st, NP, M, dinv, fail);
+        cholesky<T>(st, NP, M, dinv, fail, 1, chol_scratch_fits(NP) ? S : nullptr);
         build_sweep_matrix<T>(st, NP, nbP, M, dinv, S, tmp);         // S: sweep matrix of P
         check_fail("P (KKT initialisation)");
         HIPC(hipMemsetAsync(dual, 0, sizeof(T) * MP, st));
@@ -227,7 +227,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
             T* SchPI = M;                                            // Schur + identity on its padding
             make_PI<T>(st, (int)me, MEP, Sch, T(0), SchPI);
             T* dinv2 = dinv; T* S2 = Wl;                             // Wl no longer needed after the two GEMMs
-            cholesky<T>(st, MEP, SchPI, dinv2, fail);
+            cholesky<T>(st, MEP, SchPI, dinv2, fail, 1, chol_scratch_fits(MEP) ? S2 : nullptr);
             const int nb2 = pick(MEP);
             build_sweep_matrix<T>(st, MEP, nb2, SchPI, dinv2, S2, B);
             check_fail("A P^{-1} A' (KKT initialisation: A must have full row rank)");
