@@ -28,6 +28,9 @@ template <> struct Mfma<float> {
 
 constexpr int GT = 64;    // C tile edge per workgroup
 constexpr int GK = 16;    // K depth per LDS stage
+// k-steps of operand slabs in flight per workgroup: two for fp32 (a few per cent on every product); the fp64 kernel loses a wave of
+// occupancy to the extra registers and runs slower with more than one (tests/tools/micro/chol_chain.hip)
+template <typename T> struct GemmDepth { static constexpr int v = sizeof(T) == 4 ? 2 : 1; };
 constexpr int GLD = 80;   // LDS row stride (elements): k-groups of a fragment read land 32 banks apart
 constexpr int LPS = 20;   // row stride of the published 64 x 16 Cholesky panel: rows 16-byte aligned (b128 LDS reads in the rank-16 update)
 
@@ -53,31 +56,47 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
     // (opA(i,k) = 0 for k > i) -> stop after the diagonal tile of row block i0
     const int kbeg = (ktri == 1) ? j0 : 0;
     const int kend = (ktri == 2) ? min(K, i0 + GT) : K;
-    // opA(i0.., k0..) goes to As[k][i], opB(k0.., j0..) to Bs[k][j], 4 elements per thread each; the slab of the NEXT k-step is
-    // fetched into registers before the MFMAs of the current one (the global-load latency overlaps the multiply instead of
-    // relying on other workgroups of the CU to cover it)
-    T ga[4], gb[4];
-    auto gload = [&](int k0) {
+    // opA(i0.., k0..) goes to As[k][i], opB(k0.., j0..) to Bs[k][j], 4 elements per thread each.  The slabs of the next GemmDepth k-steps are
+    // in flight (in registers) while the current one is multiplied.
+    T ga[GemmDepth<T>::v][4], gb[GemmDepth<T>::v][4];
+    auto gload = [&](T (&xa)[4], T (&xb)[4], int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; ga[r] = A[(int64_t)(i0 + i) * lda + k0 + k]; }
-            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  ga[r] = A[(int64_t)(k0 + k) * lda + i0 + i]; }
-            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; gb[r] = B[(int64_t)(j0 + j) * ldb + k0 + k]; }
-            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  gb[r] = B[(int64_t)(k0 + k) * ldb + j0 + j]; }
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; xa[r] = A[(int64_t)(i0 + i) * lda + k0 + k]; }
+            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  xa[r] = A[(int64_t)(k0 + k) * lda + i0 + i]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; xb[r] = B[(int64_t)(j0 + j) * ldb + k0 + k]; }
+            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  xb[r] = B[(int64_t)(k0 + k) * ldb + j0 + j]; }
         }
     };
-    if (kbeg < kend) gload(kbeg);
+    // the C tile of an accumulating product is fetched first, not after the last multiply (older than every slab load: the conditional
+    // does not disturb the counting below)
+    T cv[2][2][4];
+    const bool have_c = beta != T(0);                                              // workgroup-uniform
+    if (have_c) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cv[a][b][r] = C[(int64_t)(i0 + wm * 32 + a * 16 + Mfma<T>::row(lane, r)) * ldc + j0 + wn * 32 + b * 16 + (lane & 15)];
+    }
+    // (every slab load is unconditional -- past the end the last slab is fetched again and never used -- so that the compiler's count of
+    // outstanding loads stays exact across the steps; a conditional load anywhere makes it wait for all of them at every step)
+    const int klast = max(kend - GK, 0);
+#pragma unroll
+    for (int s = 0; s < GemmDepth<T>::v; ++s) gload(ga[s], gb[s], min(kbeg + s * GK, klast));
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
+    auto step = [&](T (&xa)[4], T (&xb)[4], int kc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[buf][k][i] = ga[r]; }
-            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[buf][k][i] = ga[r]; }
-            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[buf][k][j] = gb[r]; }
-            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[buf][k][j] = gb[r]; }
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[buf][k][i] = xa[r]; }
+            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[buf][k][i] = xa[r]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[buf][k][j] = xb[r]; }
+            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[buf][k][j] = xb[r]; }
         }
         __syncthreads();   // also orders this step's reads of `buf` after the stores above, and the stores of step k+2 into `buf` after them
-        if (k0 + GK < kend) gload(k0 + GK);
+        gload(xa, xb, min(kc + GemmDepth<T>::v * GK, klast));
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4), cl = lane & 15;
@@ -88,7 +107,17 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
             acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
             acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
         }
+        buf ^= 1;
+    };
+    int k0 = kbeg;
+    for (; k0 + GemmDepth<T>::v * GK <= kend; k0 += GemmDepth<T>::v * GK) {
+#pragma unroll
+        for (int s = 0; s < GemmDepth<T>::v; ++s) step(ga[s], gb[s], k0 + s * GK);
     }
+    // remainder (depth not a multiple of GemmDepth<T>::v * 16): the registers of slot s hold step k0 + s * GK
+#pragma unroll
+    for (int s = 0; s < GemmDepth<T>::v - 1; ++s)
+        if (k0 + s * GK < kend) step(ga[s], gb[s], k0 + s * GK);
     if (tile) __syncthreads();   // the tile may live in the staging buffers: every wave must be done reading them
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -100,7 +129,7 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
                 const int col = j0 + wn * 32 + b * 16 + (lane & 15);
                 T* cp = C + (int64_t)row * ldc + col;
                 T v = alpha * acc[a][b][r];
-                if (beta != T(0)) v += beta * (*cp);
+                if (have_c) v += beta * cv[a][b][r];
                 if (tile) tile[row - i0][col - j0] = v;
                 else *cp = v;
             }

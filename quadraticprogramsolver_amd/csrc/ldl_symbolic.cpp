@@ -277,34 +277,40 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     for (int i = 0; i < N; ++i) rptr[i + 1] += rptr[i];
     { std::vector<int> pos(rptr.begin(), rptr.end() - 1); for (int j = 0; j < N; ++j) for (int k = cptr[j]; k < cptr[j + 1]; ++k) kcols[pos[rows[k]]++] = j; }
     const int Ns = S.Ns;
+    // Two sweeps over the row subtrees and one linear pass, no sorting: the first sweep counts, the second fills the CSC arrays (rows are
+    // visited in ascending order, so every column comes out sorted by row), the linear pass over the columns in ascending order then
+    // fills the CSR arrays (every row comes out sorted by column) together with the CSR -> CSC position map.
     S.rp.assign(N + 1, 0);
-    std::vector<int> stamp(N, -1), rowbuf;
+    S.cp.assign(Ns + 1, 0);
+    std::vector<int> stamp(N, -1);
     int64_t total = 0, exact = 0;
-    // first pass counts, second pass fills (the row patterns can be large; avoid a vector of vectors)
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-            if (total > 2000000000LL) throw std::runtime_error("sparse KKT LDL': the factor has more than 2^31 non-zeros under the minimum-degree ordering; use the CG plugin");
-            S.ci.resize((size_t)total);
-            std::fill(stamp.begin(), stamp.end(), -1);
-        }
-        int64_t run = 0;
-        for (int i = 0; i < N; ++i) {
-            rowbuf.clear();
-            stamp[i] = i;
-            for (int k = rptr[i]; k < rptr[i + 1]; ++k)
-                for (int j = kcols[k]; j != -1 && j < i && stamp[j] != i; j = parent[j]) { stamp[j] = i; if (j < Ns) rowbuf.push_back(j); else if (pass == 0) ++exact; }
-            if (pass == 0) { total += (int64_t)rowbuf.size(); S.rp[i + 1] = (int)std::min<int64_t>(total, 2147483647LL); }
-            else { std::sort(rowbuf.begin(), rowbuf.end()); std::copy(rowbuf.begin(), rowbuf.end(), S.ci.begin() + run); run += (int64_t)rowbuf.size(); }
-        }
+    for (int i = 0; i < N; ++i) {
+        stamp[i] = i;
+        int cnt = 0;
+        for (int k = rptr[i]; k < rptr[i + 1]; ++k)
+            for (int j = kcols[k]; j != -1 && j < i && stamp[j] != i; j = parent[j]) { stamp[j] = i; if (j < Ns) { ++cnt; S.cp[j + 1]++; } else ++exact; }
+        total += cnt;
+        S.rp[i + 1] = (int)std::min<int64_t>(total, 2147483647LL);
     }
+    if (total > 2000000000LL) throw std::runtime_error("sparse KKT LDL': the factor has more than 2^31 non-zeros under the minimum-degree ordering; use the CG plugin");
     S.nnzL_exact = total + exact;
     S.nnzL = total + (int64_t)S.Nt * (S.Nt - 1) / 2;
-    // ---- CSC of the same pattern + position map
-    S.cp.assign(Ns + 1, 0);
-    for (int64_t k = 0; k < total; ++k) S.cp[S.ci[k] + 1]++;
     for (int j = 0; j < Ns; ++j) S.cp[j + 1] += S.cp[j];
-    S.ri.resize((size_t)total); S.csr2csc.resize((size_t)total);
-    { std::vector<int> pos(S.cp.begin(), S.cp.end() - 1); for (int i = 0; i < N; ++i) for (int k = S.rp[i]; k < S.rp[i + 1]; ++k) { const int q = pos[S.ci[k]]++; S.ri[q] = i; S.csr2csc[k] = q; } }
+    S.ri.resize((size_t)total); S.ci.resize((size_t)total); S.csr2csc.resize((size_t)total);
+    {
+        std::vector<int> pos(S.cp.begin(), S.cp.end() - 1);
+        std::fill(stamp.begin(), stamp.end(), -1);
+        for (int i = 0; i < N; ++i) {
+            stamp[i] = i;
+            for (int k = rptr[i]; k < rptr[i + 1]; ++k)
+                for (int j = kcols[k]; j != -1 && j < i && stamp[j] != i; j = parent[j]) { stamp[j] = i; if (j < Ns) S.ri[pos[j]++] = i; }
+        }
+    }
+    {
+        std::vector<int> rpos(S.rp.begin(), S.rp.end() - 1);
+        for (int j = 0; j < Ns; ++j)
+            for (int q = S.cp[j]; q < S.cp[j + 1]; ++q) { const int k = rpos[S.ri[q]]++; S.ci[k] = j; S.csr2csc[k] = q; }
+    }
     // ---- where the entries of K start: CSR position (binary search in the sorted row) or dense tail position
     S.ldt = ((S.Nt + 63) / 64) * 64;
     S.k_dst.resize(ent.size()); S.k_src.resize(ent.size());

@@ -80,6 +80,19 @@ template <typename T> static void run(const char* name) {
         printf("plain update K=128 %2d x %2d     %7.2f us\n", g, g, time_chain(st, 64, [&] {
                    const T* A21 = M + (int64_t)128 * NP; T* A22 = M + (int64_t)128 * NP + 128;
                    gemm<T>(st, g * 64, g * 64, 128, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true, 1, 0, 0, 0, 0); }));
+    {   // GEMM shapes of the refactorisation (QPS_GEMM_TILE=64 forces the 64-tile kernel): checksum + time
+        auto checksum = [&](const T* d, size_t cnt) { std::vector<T> hh(cnt); hipMemcpy(hh.data(), d, sizeof(T) * cnt, hipMemcpyDeviceToHost); double a = 0; for (size_t k = 0; k < cnt; k += 7) a += (double)hh[k] * (double)((k % 13) + 1); return a; };
+        hipMemcpy(M, M0, sizeof(T) * NP * NP, hipMemcpyDeviceToDevice);
+        auto g1 = [&] { gemm<T>(st, 2048, 2048, 2048, T(1), M + (int64_t)2048 * NP, NP, true, M0, NP, false, T(0), tmp + (int64_t)2048 * NP, NP, false, 1, 0, 0, 0, 1); };
+        g1(); hipStreamSynchronize(st);
+        printf("gemm 2048^3 (L10 * W00, ktri 1)  checksum %.9e  %7.2f us\n", checksum(tmp + (int64_t)2048 * NP, (size_t)2048 * NP), time_chain(st, 8, g1));
+        auto g2 = [&] { gemm<T>(st, 2048, 2048, 2048, T(-1), M0 + (int64_t)2048 * (NP + 1), NP, true, tmp + (int64_t)2048 * NP, NP, false, T(0), S + (int64_t)2048 * NP, NP, false, 1, 0, 0, 0, 2); };
+        g2(); hipStreamSynchronize(st);
+        printf("gemm 2048^3 (W11 * tmp, ktri 2)  checksum %.9e  %7.2f us\n", checksum(S + (int64_t)2048 * NP, (size_t)2048 * NP), time_chain(st, 8, g2));
+        auto g3 = [&] { gemm<T>(st, NP, NP, NP, T(1), M0, NP, false, M0, NP, false, T(0), S, NP, true); };
+        g3(); hipStreamSynchronize(st);
+        printf("syrk 4096 x 4096 x 4096 (A'A form, lower) checksum %.9e  %7.2f us\n", checksum(S + (int64_t)3000 * NP, (size_t)64 * NP), time_chain(st, 4, g3));
+    }
     printf("cholesky 4096                 %7.2f us\n", time_chain(st, 4, [&] { hipMemcpyAsync(M, M0, sizeof(T) * NP * NP, hipMemcpyDeviceToDevice, st); cholesky<T>(st, NP, M, dinv, fail, 1); }));
     printf("  (copy alone                 %7.2f us)\n", time_chain(st, 4, [&] { hipMemcpyAsync(M, M0, sizeof(T) * NP * NP, hipMemcpyDeviceToDevice, st); }));
     printf("build_sweep_matrix 4096       %7.2f us\n", time_chain(st, 4, [&] { build_sweep_matrix<T>(st, NP, NP, M, dinv, S, tmp, 1); }));
