@@ -232,6 +232,38 @@ def test_batch_polish_with_a_count_that_does_not_divide_the_pass_grid(gpu):
         assert rel(X[b], x) <= 1e-8
 
 
+@pytest.mark.parametrize("n", [100, 130, 200, 300, 448, 1000])
+def test_cholesky_steps_at_every_block_count(gpu, n):
+    """The 128-column Cholesky steps (k_setup.hip: k_chol_step) over matrices of 2, 3, 4, 5, 7 and 16 blocks of 64: one step only, a last
+    odd 64-column step, several steps; fp64 against the host solve of M x~ = rhs (LinearSystemSolvers.jl:117-121), fp32 at its own
+    precision, and the factorisation must survive a rho switch."""
+    rng = make_rng(41, n)
+    m = n + 37
+    G = rng.standard_normal((n, n)); P = G.T @ G / n + 1e-2 * np.eye(n); A = rng.standard_normal((m, n)); q = rng.standard_normal(n)
+    for dtype, tol in (("f64", 1e-9), ("f32", 2e-3)):
+        with gpu.QuadraticProgram(P, q, A, np.zeros(m), np.zeros(m), dtype=dtype) as prob:
+            prob.linsys_init(0.3, 1e-6)
+            for changed, rho in ((False, 0.3), (True, 25.0)):
+                x, z, y = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(m)
+                xx, zz = np.zeros(n), np.zeros(m)
+                prob.linsys_solve(x, z, y, rho, 1e-6, changed, xx, zz)
+                Mh = P + 1e-6 * np.eye(n) + rho * (A.T @ A)
+                xr = np.linalg.solve(Mh, 1e-6 * x - q + A.T @ (rho * z - y))
+                assert rel(xx, xr) <= tol, (n, dtype, rho, rel(xx, xr))
+                assert rel(zz, A @ xr) <= tol
+
+
+def test_batched_cholesky_steps(gpu, c_oracle):
+    """A batch whose padded size is three blocks of 64 (a 128-column step and a last odd block, every launch carrying all QPs)."""
+    cnt, n, m = 3, 150, 170
+    probs = [GenerateDenseBenchmarkQP(n, m, stream=30 + b, feasible=True) for b in range(cnt)]
+    with gpu.QuadraticProgramBatch(probs) as batch:
+        X, flags, infos = batch.solve(numIterations=80, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
+        for b in range(cnt):
+            xo, io = c_oracle.solve(*probs[b], numIterations=80, epsAbs=0.0, epsRel=0.0, rho=0.1)
+            assert rel(X[b], xo) <= 1e-9 and infos[b]["iterations"] == 80
+
+
 def test_batch_api(gpu, c_oracle):
     """BASELINE config 4 shape in miniature: a batch advanced in lock step must reproduce per-QP independent runs --
     fixed-K iterates, and (adaptive rho) per-QP flags, stopping iterations and refactor counts."""
