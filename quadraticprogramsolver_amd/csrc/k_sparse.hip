@@ -257,6 +257,58 @@ __global__ __launch_bounds__(256) void k_spmv_combine(int nrows, const T* __rest
     }
 }
 
+// CG iteration on the blocked products, second launch: blocks [0, nbn) add up the P u partials of their 256 rows (pu), blocks beyond add up the
+// A u partials (v = A u).  Since u'(P u + sigma u + rho A'A u) = u'Pu + sigma u'u + rho v'v, the partials of dot(u, c) are complete HERE, before
+// the A' product: the x / r update then rides in the last combine of the iteration instead of a launch of its own.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_combine_pa(int n, int m, int nbn, const T* __restrict__ pp, int nblk, int64_t stride, const T* __restrict__ u,
+                                                       T sigma, T rho, T* __restrict__ pu, T* __restrict__ v, double* __restrict__ part_uc,
+                                                       const CgState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    const bool prow = (int)blockIdx.x < nbn;                                       // workgroup-uniform
+    const int row = (prow ? blockIdx.x : blockIdx.x - nbn) * 256 + threadIdx.x;
+    double d = 0.0;
+    if (row < (prow ? n : m)) {
+        const T* p0 = pp + (prow ? 0 : n) + row;
+        T s = T(0);
+#pragma unroll 8
+        for (int b = 0; b < nblk; ++b) s += p0[(int64_t)b * stride];               // independent loads, several in flight
+        if (prow) { const T ui = u[row]; pu[row] = s; d = (double)ui * ((double)s + (double)sigma * (double)ui); }
+        else { v[row] = s; d = (double)rho * (double)s * (double)s; }
+    }
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) part_uc[blockIdx.x] = d;
+}
+// ... fourth and last launch: c = pu + rho sum_b (A' v)_b + sigma u is formed in registers, alpha = res2 / dot(u, c) from the partials above (same
+// order in every block -> same alpha), x += alpha u, r -= alpha c, partials of ||r||^2 (LinearSystemSolvers.jl:179: the body of cg!)
+template <typename T>
+__global__ __launch_bounds__(256) void k_cg_combine_update(int n, const T* __restrict__ pu, const T* __restrict__ pat, int nblk, int64_t stride, T rho, T sigma,
+                                                           const T* __restrict__ u, int nparts_uc, const double* __restrict__ part_uc, T* __restrict__ x,
+                                                           T* __restrict__ r, double* __restrict__ part_rr, const CgState* __restrict__ st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    double uc = 0.0;
+    for (int i = threadIdx.x; i < nparts_uc; i += 256) uc += part_uc[i];
+    uc = block_sum_256(uc, sh);
+    const T alpha = (T)(st->res2 / uc);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double d = 0.0;
+    if (i < n) {
+        T s = T(0);
+#pragma unroll 8
+        for (int b = 0; b < nblk; ++b) s += pat[(int64_t)b * stride + i];
+        const T ui = u[i];
+        const T c = pu[i] + rho * s + sigma * ui;
+        x[i] += alpha * ui;
+        const T ri = r[i] - alpha * c;
+        r[i] = ri;
+        d = (double)ri * (double)ri;
+    }
+    d = block_sum_256(d, sh);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = d;
+}
+
 // r = b - c, u = 0, partial ||r||^2
 template <typename T>
 __global__ __launch_bounds__(256) void k_cg_init(int n, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ r,
@@ -565,7 +617,7 @@ template <typename T> struct SparseSolver : SolverBase {
         l = dalloc<T>(mm, st); u = dalloc<T>(mm, st); z = dalloc<T>(mm, st); zp = dalloc<T>(mm, st); y = dalloc<T>(mm, st); zz = dalloc<T>(mm, st);
         w = dalloc<T>(mm, st); tm = dalloc<T>(mm, st); Ax = dalloc<T>(mm, st);
         nb_n = (int)((n + 255) / 256);
-        part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n) + 64, st); part_rr = dalloc<double>(nb_n + 64, st);
+        part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n + (int)((m + 255) / 256)) + 64, st); part_rr = dalloc<double>(nb_n + 64, st);
         state = reinterpret_cast<CgState*>(dalloc<double>(16, st));
         state_host = reinterpret_cast<CgState*>(res.pinned);                          // pinned block: CG state | check results
         scratch = dalloc<unsigned long long>(16, st); res_dev = dalloc<double>(16, st);
@@ -670,11 +722,13 @@ template <typename T> struct SparseSolver : SolverBase {
                     { ProfLaunchScope ps2(prof, cat_pa, sample ? 1 : 3); spmv_blk(PA, cr, nullptr, fu); }
                     cur ^= 1; ui ^= 1;
                     const T* pp = static_cast<const T*>(PA.partial);
-                    hipLaunchKernelGGL((k_spmv_combine<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (int)m, pp + n, PA.nblk, (int64_t)(n + m), T(1),
-                                       (const T*)nullptr, 0, (int64_t)0, T(0), (const T*)nullptr, T(0), (const T*)nullptr, T(0), tm, (const T*)nullptr, (double*)nullptr, slot[cur]);
+                    const int nb_m = (int)((m + 255) / 256);
+                    hipLaunchKernelGGL((k_cg_combine_pa<T>), dim3((unsigned)(nb_n + nb_m)), dim3(256), 0, st, (int)n, (int)m, nb_n, pp, PA.nblk, (int64_t)(n + m), ub[ui],
+                                       (T)sigma, (T)rho, cc, tm, part_uc, slot[cur]);                       // cc = P u, tm = A u, partials of dot(u, c)
                     { ProfLaunchScope ps2(prof, cat_at, sample ? 1 : 3); spmv_blk(At, tm, slot[cur]); }
-                    hipLaunchKernelGGL((k_spmv_combine<T>), dim3(nb_n), dim3(256), 0, st, (int)n, pp, PA.nblk, (int64_t)(n + m), T(1),
-                                       static_cast<const T*>(At.partial), At.nblk, (int64_t)n, (T)rho, ub[ui], (T)sigma, (const T*)nullptr, T(0), cc, ub[ui], part_uc, slot[cur]);
+                    hipLaunchKernelGGL((k_cg_combine_update<T>), dim3(nb_n), dim3(256), 0, st, (int)n, cc, static_cast<const T*>(At.partial), At.nblk, (int64_t)n, (T)rho,
+                                       (T)sigma, ub[ui], nb_n + nb_m, part_uc, xx, cr, part_rr, slot[cur]);
+                    continue;
                 } else {
                     hipLaunchKernelGGL((k_cg_next_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_n, part_rr, cr, ub[ui], slot[cur], slot[cur ^ 1], b == 0 ? 1 : 0);
                     cur ^= 1;
