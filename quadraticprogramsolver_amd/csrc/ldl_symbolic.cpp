@@ -3,7 +3,9 @@
 #include "ldl_symbolic.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <stdexcept>
@@ -186,6 +188,11 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     LdlSymbolic S;
     S.n = n; S.m = m; S.N = n + m;
     const int N = S.N;
+    // QPS_LDL_TIMING=1: phase times of the analysis on stderr (tests/tools/cpu_ldl_analyze_timing.py)
+    const bool timing = [] { const char* e = getenv("QPS_LDL_TIMING"); return e && atoi(e) != 0; }();
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = timing ? now() : 0.0;
+    auto lap = [&](const char* what) { if (timing) { const double t = now(); fprintf(stderr, "[ldl_analyze] %-34s %7.2f ms\n", what, t - t_last); t_last = t; } };
     const int64_t pnnz = Pcp[n] - base, annz = Acp[n] - base;
     // ---- entries of the strictly lower triangle of K in the ORIGINAL numbering ([x; nu]); value table = P entries, then A entries
     std::vector<KEntry> ent; ent.reserve((size_t)(pnnz / 2 + annz));
@@ -199,6 +206,7 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     for (int j = 0; j < n; ++j)
         for (int64_t k = Acp[j] - base; k < Acp[j + 1] - base; ++k) ent.push_back({n + (int)(Ari[k] - base), j, (int)(pnnz + k)});
     S.nnzK = (int64_t)ent.size();
+    lap("entries of K");
     // ---- ordering
     {
         std::vector<std::vector<int>> adj(N);
@@ -207,7 +215,9 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
         for (int i = 0; i < N; ++i) adj[i].reserve(cnt[i]);
         for (const KEntry& e : ent) { adj[e.row].push_back(e.col); adj[e.col].push_back(e.row); }
         for (int i = 0; i < N; ++i) { std::sort(adj[i].begin(), adj[i].end()); adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end()); }
+        lap("adjacency lists");
         S.perm = amd_order(N, adj);
+        lap("minimum-degree ordering");
     }
     std::vector<int> ip(N);
     for (int k = 0; k < N; ++k) ip[S.perm[k]] = k;
@@ -238,6 +248,7 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     std::vector<int> cptr, rows, parent;
     lower_cols(ip, cptr, rows);
     etree(cptr, rows, parent);
+    lap("elimination tree");
     // ---- levels (leaves = 0) and the equivalent reordering "by level, then by position"
     std::vector<int> level(N, 0);
     for (int j = 0; j < N; ++j) if (parent[j] >= 0) level[parent[j]] = std::max(level[parent[j]], level[j] + 1);   // children precede parents
@@ -269,6 +280,7 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     for (int k = 0; k < N; ++k) S.sign[k] = S.perm[k] < n ? 1 : -1;
     S.dpos_P.resize(N);
     for (int k = 0; k < N; ++k) S.dpos_P[k] = S.perm[k] < n ? dposP[S.perm[k]] : -1;
+    lap("levels + composed permutation");
     // ---- pattern of L by rows in the final numbering: row i = union of the etree paths from the non-zeros of row i of K
     lower_cols(S.iperm, cptr, rows);
     etree(cptr, rows, parent);
@@ -311,6 +323,7 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
         for (int j = 0; j < Ns; ++j)
             for (int q = S.cp[j]; q < S.cp[j + 1]; ++q) { const int k = rpos[S.ri[q]]++; S.ci[k] = j; S.csr2csc[k] = q; }
     }
+    lap("pattern of L (CSC + CSR)");
     // ---- where the entries of K start: CSR position (binary search in the sorted row) or dense tail position
     S.ldt = ((S.Nt + 63) / 64) * 64;
     S.k_dst.resize(ent.size()); S.k_src.resize(ent.size());
@@ -325,6 +338,7 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
             S.k_dst[e] = (int64_t)(it - S.ci.data());
         } else S.k_dst[e] = -(1 + (int64_t)(i - Ns) * S.ldt + (j - Ns));
     }
+    lap("scatter map of K");
     return S;
 }
 
