@@ -115,7 +115,9 @@ typedef struct {
     int32_t trsvBlock;       /* dense handles: size of the inverted diagonal blocks the triangular sweeps ran with (0: not a dense Cholesky run) */
     int32_t sweepVariant;    /* dense handles: 1 = blocked substitution over the sweep matrix (2 n / trsvBlock - 1 dependent phases per sweep),
                                 2 = explicit inverse, both sweeps fused into one pass over the triangle (trsvBlock >= n),
-                                3 = explicit inverse, two triangular GEMVs, 4 = single-launch small-problem loop; 0 otherwise */
+                                3 = explicit inverse, two triangular GEMVs, 4 = single-launch small-problem loop,
+                                5 = blocked substitution, ONE launch per sweep (n / trsvBlock dependent phases handed from workgroup to
+                                    workgroup inside the launch; trsvBlock = 1024 or 512 fp64, 2048 or 1024 fp32); 0 otherwise */
 } qps_info;
 
 /* Fill *p with the reference defaults (SolveQuadraticProgram.jl:15-17). */

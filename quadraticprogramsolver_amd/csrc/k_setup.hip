@@ -4,6 +4,7 @@
 // (dense Cholesky + in-place re-factorisation precedent).
 #include "qps_kernels.h"
 #include "wave_reduce.h"
+#include <algorithm>
 
 namespace qps {
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
     const int i0 = bi * GT, j0 = bj * GT;
     // ktri 1: opB is lower triangular (opB(k,j) = 0 for k < j) -> start at k = j0;  ktri 2: opA is lower triangular
     // (opA(i,k) = 0 for k > i) -> stop after the diagonal tile of row block i0
-    const int kbeg = (ktri == 1) ? j0 : 0;
+    const int kbeg = (ktri == 1) ? j0 : (ktri == 3 ? i0 : 0);   // ktri 3: opA is upper triangular (opA(i,k) = 0 for k < i)
     const int kend = (ktri == 2) ? min(K, i0 + GT) : K;
     // opA(i0.., k0..) goes to As[k][i], opB(k0.., j0..) to Bs[k][j], 4 elements per thread each.  The slabs of the next GemmDepth k-steps are
     // in flight (in registers) while the current one is multiplied.
@@ -656,9 +657,10 @@ __global__ void k_init_sweep(int NP, const T* __restrict__ L, const T* __restric
 }
 // S[j][i] = S[i][j] for j < i, 64 x 64 tiles through LDS
 template <typename T>
-__global__ __launch_bounds__(256) void k_mirror(int NP, T* __restrict__ S) {
+__global__ __launch_bounds__(256) void k_mirror(int NP, T* __restrict__ S, int blk_tiles) {
     const int bj = blockIdx.x, bi = blockIdx.y;
     if (bj > bi) return;
+    if (blk_tiles > 0 && bi / blk_tiles != bj / blk_tiles) return;   // premultiplied form: only the diagonal blocks are mirrored
     S += (int64_t)blockIdx.z * NP * NP;
     __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -739,7 +741,7 @@ template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* 
 
 // batch > 1: L, S and tmp hold `batch` matrices NP*NP apart.  The doubling GEMMs are batched over the QPs (blockIdx.z) and
 // looped over the pairs of a level on the host (pairs x QPs would need two batch strides).
-template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp, int batch) {
+template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp, int batch, bool premul) {
     const int64_t sM = (int64_t)NP * NP, sD = (int64_t)(NP / 64) * 4096;
     hipLaunchKernelGGL((k_init_sweep<T>), dim3((NP + 255) / 256, NP, batch), dim3(256), 0, st, NP, L, dinv, S, sD);
     // recursive doubling: inv([L00 0; L10 L11]) = [inv00 0; -inv11 L10 inv00, inv11]
@@ -767,7 +769,24 @@ template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, co
             gemm<T>(st, s2, s, s2, T(-1), S + (int64_t)(o + s) * (NP + 1), NP, true, t10, NP, false, T(0), S + (int64_t)(o + s) * NP + o, NP, false, batch, sM, sM, sM, 2);
         }
     }
-    hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64, batch), dim3(256), 0, st, NP, S);
+    if (premul && batch == 1 && nb < NP) {
+        // Block rows pre-multiplied by their inverted diagonal block (k_trsv_blocked.hip): one dependent phase per block row.
+        //   upper blocks of block row J:  -(L[(J+1)nb.., J] W_JJ)'  = -W_JJ' L[.., J]'   (W_JJ' upper triangular: ktri 3; S upper is still zero)
+        //   lower blocks of block row J:  -W_JJ L[J, 0 .. J nb)                          (W_JJ lower triangular: ktri 2)
+        const int nblk = (NP + nb - 1) / nb;
+        for (int J = 0; J + 1 < nblk; ++J) {
+            const int64_t r0 = (int64_t)J * nb, c0 = r0 + nb;
+            gemm<T>(st, nb, (int)(NP - c0), nb, T(-1), S + r0 * (NP + 1), NP, false, L + c0 * NP + r0, NP, true, T(0), S + r0 * NP + c0, NP, false, 1, 0, 0, 0, 3);
+        }
+        for (int J = 1; J < nblk; ++J) {
+            const int64_t r0 = (int64_t)J * nb;
+            const int rows = (int)std::min<int64_t>(nb, NP - r0);
+            gemm<T>(st, rows, (int)r0, rows, T(-1), S + r0 * (NP + 1), NP, true, L + r0 * NP, NP, false, T(0), S + r0 * NP, NP, false, 1, 0, 0, 0, 2);
+        }
+        hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64, batch), dim3(256), 0, st, NP, S, nb / 64);
+        return;
+    }
+    hipLaunchKernelGGL((k_mirror<T>), dim3(NP / 64, NP / 64, batch), dim3(256), 0, st, NP, S, 0);
 }
 
 #define INST(T)                                                                                                        \
@@ -777,7 +796,7 @@ template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, co
     template void make_PI<T>(hipStream_t, int, int, const T*, T, T*, int);                                             \
     template void assemble_M<T>(hipStream_t, int, const T*, const T*, T, T*, int, const double*);                      \
     template void cholesky<T>(hipStream_t, int, T*, T*, int*, int, T*);                                                    \
-    template void build_sweep_matrix<T>(hipStream_t, int, int, const T*, const T*, T*, T*, int);
+    template void build_sweep_matrix<T>(hipStream_t, int, int, const T*, const T*, T*, T*, int, bool);
 INST(double)
 INST(float)
 #undef INST

@@ -79,6 +79,9 @@ template <typename T> struct DenseSolver : SolverBase {
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
     int nb = 2048; int part_tiles = 0; int num_factorizations = 0;
+    // single-launch blocked sweeps (k_trsv_blocked.hip): hand-off granules, launch epoch, give-up word; `blocked_off` after a launch gave up
+    unsigned long long* pub = nullptr; unsigned* abort_dev = nullptr; unsigned sweep_epoch = 0; bool blocked_off = false, fac_premul = false;
+    bool use_blocked() const { return !blocked_off && trsv_blocked_supported<T>(NP, nb); }
     // hipGraph replay of runs of plain iterations (no check, no rho switch) for problems small enough to be launch bound
     struct IterGraph { int count; const void* xa; double rho, sigma, alpha; int nb; hipGraphExec_t exec; };
     std::vector<IterGraph> graphs;
@@ -132,6 +135,8 @@ template <typename T> struct DenseSolver : SolverBase {
             sw_part = ar.take<T>((int64_t)std::max(sweep_fused_slabs<T>(NP), 1) * NP);
             Ax = ar.take<T>(MP); Px = ar.take<T>(NP); Aty = ar.take<T>(NP);
             scratch = ar.take<unsigned long long>(16); res_dev = ar.take<double>(16);
+            pub = ar.take<unsigned long long>(trsv_blocked_pub_words<T>(NP));
+            abort_dev = reinterpret_cast<unsigned*>(res_dev + 14);   // rides in the check's read-back (slots 8..15 are unused by the check kernels)
             stage = ar.take<double>((int64_t)NP + 2 * (int64_t)MP + 64);
             if (small_ok) { At = ar.take<T>((int64_t)NP * MP); small_out = ar.take<double>(32); }
             if (stage_mat_count > 0) stage_mat = ar.take<double>(stage_mat_count);
@@ -219,7 +224,7 @@ template <typename T> struct DenseSolver : SolverBase {
         }
         assemble_M<T>(st, NP, PI, AA, (T)rho, M);                                                    // :114 / :128
         cholesky<T>(st, NP, M, dinv, fail, 1, chol_scratch_fits(NP) ? S : nullptr);   // S is rebuilt right after: free as scratch
-        build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp);
+        build_sweep_matrix<T>(st, NP, nb, M, dinv, S, tmp, 1, use_blocked());
         int f = 0;
         HIPC(hipMemcpyAsync(&f, fail, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
@@ -229,11 +234,26 @@ template <typename T> struct DenseSolver : SolverBase {
             char b[256]; snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A broke down: non-positive pivot at column %d (rho=%g, sigma=%g; factorisation #%d of this handle)", f, rho, sigma, num_factorizations);
             throw QpsError(QPS_ERR_FACTORIZATION, b);
         }
-        factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb;
+        factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb; fac_premul = use_blocked();
+    }
+    // Did a blocked-sweep launch give up waiting (workgroups not co-resident, e.g. a card shared with another process)?  Then the iterates
+    // are garbage: the handle drops to the multi-launch sweeps for good and the caller repeats its work.  Synchronises the stream.
+    bool sweep_gave_up(bool fetched = false) {
+        if (!fac_premul) return false;
+        unsigned* h = reinterpret_cast<unsigned*>(res_host + 14);
+        if (!fetched) {
+            HIPC(hipMemcpyAsync(h, abort_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            HIPC(hipStreamSynchronize(st));
+        }
+        if (*h == 0u) return false;
+        HIPC(hipMemsetAsync(abort_dev, 0, sizeof(unsigned), st));
+        blocked_off = true; factor_valid = false;
+        return true;
     }
 
     int sweep_variant() const {
         const int nblk = (NP + nb - 1) / nb;
+        if (nblk > 1 && fac_premul) return 5;
         static const int sweep_mode = getenv("QPS_SWEEP_MODE") ? atoi(getenv("QPS_SWEEP_MODE")) : 2;
         if (nblk == 1) return (sweep_mode == 2 && sweep_fused_supported<T>(NP)) ? 2 : 3;
         return 1;
@@ -247,6 +267,12 @@ template <typename T> struct DenseSolver : SolverBase {
             int G;
             { ProfLaunchScope ps(prof, cat_sweep, sample_lvl(13)); G = sweep_fused<T>(st, S, NP, NP, tt, sw_part, NP); }
             { ProfLaunchScope ps(prof, cat_xsum, sample_lvl(21)); colsum<T>(st, sw_part, NP, G, nullptr, T(0), nullptr, T(0), xx, NP); }
+            return;
+        }
+        if (fac_premul) {
+            // blocked substitution, one launch per sweep: n / nb dependent phases handed from workgroup to workgroup inside the launch
+            { ProfLaunchScope ps(prof, cat_fwd, sample_lvl(13)); trsv_blocked<T>(st, false, S, NP, NP, nb, tt, yv, pub, ++sweep_epoch, abort_dev); }
+            { ProfLaunchScope ps(prof, cat_bwd, sample_lvl(21)); trsv_blocked<T>(st, true, S, NP, NP, nb, yv, xx, pub, ++sweep_epoch, abort_dev); }
             return;
         }
         {
@@ -292,7 +318,7 @@ template <typename T> struct DenseSolver : SolverBase {
         double rho = p.rho, sigma = p.sigma; const double alpha = p.alpha;
         const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;                                // SolveQuadraticProgram.jl:34
         int convFlag = QPS_CONV_NUM_ITR;                                                            // :33
-        const bool reuse = p.reuseFactor && factor_valid && fac_rho == rho && fac_sigma == sigma && fac_nb == nb;
+        const bool reuse = p.reuseFactor && factor_valid && fac_rho == rho && fac_sigma == sigma && fac_nb == nb && fac_premul == use_blocked();
         if (!reuse) factorize(rho, sigma, !p.reuseFactor || !have_AA || fac_sigma != sigma);        // :36
         upload_vec(xh, x, n);
         HIPC(hipMemsetAsync(xp, 0, sizeof(T) * NP, st));                                            // :38
@@ -347,7 +373,8 @@ template <typename T> struct DenseSolver : SolverBase {
         // Launch-bound sizes (an iteration of four to eight kernels lasts less than the host needs to enqueue it): replay graphs.
         // Profiling brackets launches and stays eager.
         static const int graph_env = [] { const char* e = getenv("QPS_GRAPH"); return e ? atoi(e) : -1; }();
-        const bool use_graph = fused && prof.level == 0 && p.numItrConv >= 3 && (graph_env >= 0 ? graph_env != 0 : NP <= 2048);
+        // (the blocked sweeps take a fresh epoch argument per launch: no replay)
+        const bool use_graph = fused && prof.level == 0 && p.numItrConv >= 3 && !fac_premul && (graph_env >= 0 ? graph_env != 0 : NP <= 2048);
         for (ii = 1; ii <= p.numIterations; ++ii) {                                                 // :45
             bool changed = false;
             if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {          // :47
@@ -414,15 +441,17 @@ template <typename T> struct DenseSolver : SolverBase {
                 }
             }
             if (check) {
-                HIPC(hipMemcpyAsync(res_host, res_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPC(hipMemcpyAsync(res_host, res_dev, 15 * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPC(hipStreamSynchronize(st));
                 prof.harvest();
+                if (sweep_gave_up(true)) { solve(xh, p, info); return; }                                // x on the host is still the caller's
                 resP = res_host[0]; resD = res_host[1]; rhorho = res_host[4]; convFlag = (int)res_host[5];
                 if (convFlag != QPS_CONV_NUM_ITR) break;                                            // :66-68
             }
         }
         HIPC(hipStreamSynchronize(st));
         prof.harvest();
+        if (sweep_gave_up()) { solve(xh, p, info); return; }
         const double t2 = now_s();
         PolishReport pr;
         if (p.polish) polish_dense<T>(st, n, m, NP, MP, P, A, q, l, u, y, x, part, p, &pr);        // SolveQuadraticProgram.m:289-325
@@ -464,6 +493,7 @@ template <typename T> struct DenseSolver : SolverBase {
         if (changed) factorize(rho, sigma, false);                                                  // LinearSystemSolvers.jl:127-129
         upload_vec(xh, x, n); upload_vec(zh, z, m); upload_vec(yh, y, m);
         linear_solve(rho, sigma);
+        if (sweep_gave_up()) { factorize(rho, sigma, false); linear_solve(rho, sigma); }
         download_vec(xx, xxh, n); download_vec(zz, zzh, m);
     }
 };

@@ -152,6 +152,18 @@ template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* 
 
 // Build the sweep matrix S from L (lower of M) and the 64-block inverses: diagonal nb-blocks inverted by recursive
 // doubling, then mirrored into the upper triangle.  tmp: NP x NP scratch.
-template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp, int batch = 1);
+// premul (single matrix, nb < NP): every block row is additionally multiplied by its inverted diagonal block and negated off the diagonal
+// (lower blocks -W_JJ L_JK, upper blocks -(L_KJ W_JJ)'): the form the single-launch blocked sweeps read (k_trsv_blocked.hip).
+template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, const T* L, const T* dinv, T* S, T* tmp, int batch = 1, bool premul = false);
+
+// ---- blocked triangular substitution, one launch per sweep (k_trsv_blocked.hip) ----------------------------------------------------
+// out = forward (bwd = false: rows of S left of and inside the diagonal block) or backward (bwd = true) sweep over the PREMULTIPLIED sweep
+// matrix with nb x nb blocks.  pub: trsv_blocked_pub_words<T>(NP) 64-bit words, zero-filled once (hand-off granules); epoch: a value that grows
+// with every launch on this pub buffer (never 0); abort_word: set to 1 by a launch that gave up waiting (its `out` is garbage then).
+template <typename T> bool trsv_blocked_supported(int NP, int nb);
+template <typename T> int64_t trsv_blocked_pub_words(int NP);
+template <typename T>
+void trsv_blocked(hipStream_t st, bool bwd, const T* S, int64_t ld, int NP, int nb, const T* v, T* out, unsigned long long* pub,
+                  unsigned epoch, unsigned* abort_word, int mode = 0);
 
 }  // namespace qps
