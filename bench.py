@@ -32,7 +32,8 @@ CONFIGS = {
     "c4": dict(n=1024, m=2048, dtype="f64", batch=256, label="batch of 256 dense n=1024 m=2048 QPs sharded across the ranks (configs[3])"),
 }
 SWEEP_VARIANTS = {0: None, 1: "blocked substitution (2n/nb-1 dependent phases per sweep)", 2: "explicit inverse, both sweeps fused into one pass over the triangle",
-                  3: "explicit inverse, two triangular GEMVs", 4: "single-launch small-problem loop"}
+                  3: "explicit inverse, two triangular GEMVs", 4: "single-launch small-problem loop",
+                  5: "blocked substitution, one launch per sweep (n/nb dependent phases handed over inside the launch)"}
 
 
 def spawn_ranks_if_needed(args, argv):
@@ -197,6 +198,19 @@ def run_dense(args, cfg, info, device, qps, qd, np, sync):
                                      "GBs": round(sw["algo_bytes"] / dur / 1e9, 1), "frac_of_8TBs": round(sw["algo_bytes"] / dur / 1e9 / HBM_PEAK_GBS, 4),
                                      "two_sweep_algo_bytes": s * (n * (n + 1) + 4 * n), "two_sweep_algo_GBs": round(s * (n * (n + 1) + 4 * n) / dur / 1e9, 1),
                                      "traffic": t_sw, "traffic_frac_of_8TBs": round(t_sw / dur / 1e9 / HBM_PEAK_GBS, 4) if t_sw else None, "traffic_source": src_sw}
+        bl = [k for k in ktimes if k["name"] in ("trsv_forward", "trsv_backward") and k["launches"] > 0]
+        if bl and last.get("sweepVariant") == 5:
+            # --trsv-block 1024 (fp64) / 2048 (fp32): the back-substitution kernel north_star names.  One launch per sweep; SURVEY §8d's
+            # per-sweep figure s*(n(n+1)/2 + 2n) is what each launch has to move.  PMC traffic: profiles/r*pmc_traffic_<config>_trsv<nb>.json
+            ent = []
+            for k in bl:
+                dur = k["seconds"] / k["launches"]
+                t_k, src_k = pmc_traffic(f"{args.config}_trsv{last.get('trsvBlock')}", r"k_trsv_blocked<.*" + ("true" if k["name"].endswith("backward") else "false") + r", \d+>")
+                ent.append({"kernel": f"k_trsv_blocked ({k['name']})", "avg_launch_us": round(dur * 1e6, 2), "launches_timed": k["launches"], "algo_bytes": k["algo_bytes"],
+                            "GBs": round(k["algo_bytes"] / dur / 1e9, 1), "frac_of_8TBs": round(k["algo_bytes"] / dur / 1e9 / HBM_PEAK_GBS, 4),
+                            "traffic": t_k, "traffic_frac_of_8TBs": round(t_k / dur / 1e9 / HBM_PEAK_GBS, 4) if t_k else None, "traffic_source": src_k})
+            out["sweep_roofline"] = {"variant": SWEEP_VARIANTS[5], "trsv_block": last.get("trsvBlock"), "dependent_phases_per_sweep": -(-n // last.get("trsvBlock")),
+                                     "sweeps": ent, "target": ">= 0.40 of the 8 TB/s HBM roofline on the back-substitution kernel (BASELINE north_star)"}
         if not args.no_time_to_eps and args.config in ("c2", "c5"):
             # time-to-eps on the feasible variant (the plain m = 2n draw is primal infeasible: see generator docstring); fp32 to 1e-4
             Pf, qf, Af, lf, uf = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank, feasible=True)

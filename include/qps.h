@@ -73,7 +73,10 @@ typedef struct {
     int32_t numItrMinres;    /* 500; polishing only */
     int32_t linsys;          /* qps_linsys_kind, additive, default AUTO */
     int32_t trsvBlock;       /* additive: size of the inverted diagonal blocks of the blocked triangular sweep; a
-                                power-of-two multiple of 64, 0 = library default min(4096, n padded)                  */
+                                power-of-two multiple of 64, 0 = library default: one inverted block over the whole factor
+                                while the fused forward+backward sweep covers n (n padded <= 16384 fp64 / 32768 fp32), else 4096.
+                                1024 or 512 (fp64) / 2048 or 1024 (fp32) with n above it: blocked substitution, ONE launch per
+                                sweep (qps_info.sweepVariant = 5); other sizes below n: one launch per block phase (1)         */
     int32_t reuseFactor;     /* additive: 1 = keep the factorisation of a previous qps_solve/linsys_init when
                                 (rho, sigma) are unchanged; 0 = factorise on every call like the reference (:36)      */
     double epsAbs;           /* ϵAbs 1e-6 */
