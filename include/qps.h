@@ -221,8 +221,11 @@ int32_t qps_proxqp_create_dense(int64_t n, int64_t numEq, int64_t numInEq, const
                                 const double *A, int64_t lda, const double *b, const double *C, int64_t ldc, const double *d,
                                 int32_t dtype, int32_t device, qps_handle *out);
 /* SparseProxQP (ProxQP.jl:71, :95-115): the same with the colptr / rowval / nzval fields of three SparseMatrixCSC inputs (index_base 1 for
- * Julia).  The matrices are densified and take the dense path; the in-place dense re-factorisation (ProxQP.jl:193-199) stands in for the
- * pattern-reusing sparse cholesky! of :201-206. */
+ * Julia).  The matrices stay sparse: the linear system of UpdateX! (:221-225) is solved in its KKT form [P + sigma I, G'; G, -I/rho], G = [A; C],
+ * by the sparse L D L' plugin -- ordering and symbolic factor once per handle, a rho update re-factorises numerically on the frozen pattern
+ * (the role of AlignSparsePattern / GetNzvalDiagIdxs / UpdateM! / the pattern-reusing cholesky!, :184-190, :201-206, :335-372).
+ * qps_proxqp_init_kkt on such a handle: sparse factor of [P A'; A -1e-8 I] + iterative refinement against [P A'; A 0] (:95-115).
+ * QPS_ERR_UNSUPPORTED at the first solve / init when the factor does not fit the level-scheduled plugin (then: the dense constructor). */
 int32_t qps_proxqp_create_csc(int64_t n, int64_t numEq, int64_t numInEq, const int64_t *P_colptr, const int64_t *P_rowval, const double *P_nzval,
                               const double *q, const int64_t *A_colptr, const int64_t *A_rowval, const double *A_nzval, const double *b,
                               const int64_t *C_colptr, const int64_t *C_rowval, const double *C_nzval, const double *d, int32_t index_base,

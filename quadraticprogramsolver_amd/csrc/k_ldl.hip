@@ -123,6 +123,22 @@ __global__ __launch_bounds__(256) void k_ldl_rhs(int N, int n, const int* __rest
     const int o = perm[k];
     b[k] = o < n ? sigma * x[o] - q[o] : z[o - n] - rho1 * y[o - n];          // LinearSystemSolvers.jl:37-38
 }
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_rhs_raw(int N, int n, const int* __restrict__ perm, const T* __restrict__ r1, const T* __restrict__ r2, T* __restrict__ b) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    const int o = perm[k];
+    b[k] = o < n ? r1[o] : r2[o - n];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_post_raw(int n, int m, int Ns, const int* __restrict__ iperm, const T* __restrict__ b, const T* __restrict__ tx,
+                                                      T* __restrict__ ox, T* __restrict__ onu) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n + m) return;
+    const int k = iperm[o];
+    const T v = k >= Ns ? tx[k - Ns] : b[k];
+    if (o < n) ox[o] = v; else onu[o - n] = v;
+}
 template <typename T, int LPR> __device__ __forceinline__ T group_sum(T s) {
     if (LPR == 4) return quad_sum_all(s);
     if (LPR == 16) return row16_sum_last(s);       // valid in the last lane of the group
@@ -444,6 +460,12 @@ template <typename T> struct SparseLdlImpl : SparseLdl<T> {
         sweeps();
         hipLaunchKernelGGL((k_ldl_post_update<T>), dim3((N + 255) / 256), dim3(256), 0, st, S.n, S.m, S.Ns, iperm.p, b.p, tx.p, q, x, xp, z, zp, y, l, u,
                            (T)alpha, (T)rho, (T)sigma);
+    }
+    void solve_raw(const T* r1, const T* r2, T* out_x, T* out_nu) override {
+        const int N = S.N;
+        hipLaunchKernelGGL((k_ldl_rhs_raw<T>), dim3((N + 255) / 256), dim3(256), 0, st, N, S.n, perm.p, r1, r2, b.p);
+        sweeps();
+        hipLaunchKernelGGL((k_ldl_post_raw<T>), dim3((N + 255) / 256), dim3(256), 0, st, S.n, S.m, S.Ns, iperm.p, b.p, tx.p, out_x, out_nu);
     }
     void solve(const T* x, const T* q, const T* z, const T* y, double rho, double sigma, T* xx, T* zz) override {
         const int N = S.N;

@@ -18,6 +18,8 @@
 #include "qps_kernels.h"
 #include "qps_ldl.h"
 #include "qps_polish.h"
+#include "qps_proxqp.h"
+#include "k_proxqp_rows.h"
 #include "wave_reduce.h"
 #include <hip/hip_ext.h>
 
@@ -892,7 +894,168 @@ template <typename T> struct SparseSolver : SolverBase {
     }
 };
 
+
+// =================================================================================================================
+// SparseProxQP (ProxQP.jl:71, :95-115; sparse branches :184-190, :201-206, :335-372): the second solver form on SparseMatrixCSC inputs.
+//
+// The reference keeps M = P + rho (A'A + C'C) + sigma I as a sparse matrix with a frozen pattern (AlignSparsePattern :351-372, diagonal
+// positions :335-349), rewrites its values on a rho update (UpdateM! :184-190) and re-factorises with the pattern-reusing `cholesky!`
+// (:201-206).  Here the same linear system is solved in its KKT form
+//     [P + sigma I   G' ; G   -I / rho] [x ; nu] = [sigma x - q ; h - dual / rho],     G = [A; C],  h = [b ; d - s],  dual = [y ; z]
+// (eliminating nu gives exactly M x = sigma x - q + G'[rho b - y ; rho (d - s) - z], CalculateRhs! :208-219) with the sparse L D L' plugin
+// of the main path: ordering + symbolic factor once per handle, a rho update is numeric only -- the pattern-reusing re-factorisation --
+// and G x, which the row updates (:227-249) need, comes back with the solve (z~ = z + (nu - y) / rho = G x).  G'G is never formed: the
+// reduced matrix of a sparse G is much denser than [.. G'; G ..].  CheckConvergence! (:252-298) runs on the CSR SpMVs of the main path.
+// The six-argument constructor's start (:95-115: [P A'; A 0] [x; y] = [-q; b]) uses a second factor, of [P A'; A -delta I], and iterative
+// refinement against the unperturbed system.
+// =================================================================================================================
+template <typename T> struct SparseProxQpSolver : ProxQpBase {
+    std::unique_ptr<SparseSolver<T>> ss;          // P, G = [A; C] as CSR (G, G'), the L D L' plugin, the staging buffers
+    hipStream_t st = nullptr;
+    int mtot = 0;
+    T *g = nullptr, *dual = nullptr, *slack = nullptr, *hvec = nullptr, *x = nullptr, *xx = nullptr, *v = nullptr, *de = nullptr, *di = nullptr;
+    T *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *r1 = nullptr, *r2 = nullptr, *dx = nullptr, *dnu = nullptr, *zero_m = nullptr;
+    unsigned long long* slots = nullptr; unsigned long long* slots_host = nullptr;
+    // canonical 0-based host copies of P and A for the factor of the initialisation (dropped after init_kkt / set_state)
+    std::vector<int64_t> kPcp, kPri, kAcp, kAri; std::vector<double> kPnz, kAnz;
+
+    static dim3 g1(int64_t c) { return dim3((unsigned)((std::max<int64_t>(c, 1) + 255) / 256)); }
+
+    SparseProxQpSolver(int dev, int64_t n_, int64_t me_, int64_t mi_, int dt, const int64_t* Pcp, const int64_t* Pri, const double* Pnz, const double* qh,
+                       const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* bh, const int64_t* Ccp, const int64_t* Cri, const double* Cnz,
+                       const double* dh, int base) {
+        device = dev; n = n_; me = me_; mi = mi_; mtot = (int)(me + mi);
+        // G = [A; C] column by column (rows of C shifted by numEq), 0-based; P re-based
+        std::vector<int64_t> Gcp(n + 1, 0), Gri, P0cp(n + 1), P0ri((size_t)(Pcp[n] - base));
+        std::vector<double> Gnz;
+        for (int64_t j = 0; j <= n; ++j) P0cp[j] = Pcp[j] - base;
+        for (size_t k = 0; k < P0ri.size(); ++k) P0ri[k] = Pri[k] - base;
+        for (int64_t j = 0; j < n; ++j) {
+            if (me > 0) for (int64_t k = Acp[j] - base; k < Acp[j + 1] - base; ++k) { Gri.push_back(Ari[k] - base); Gnz.push_back(Anz[k]); }
+            if (mi > 0) for (int64_t k = Ccp[j] - base; k < Ccp[j + 1] - base; ++k) { Gri.push_back(Cri[k] - base + me); Gnz.push_back(Cnz[k]); }
+            Gcp[j + 1] = (int64_t)Gri.size();
+        }
+        std::vector<double> zeros((size_t)std::max(mtot, 1), 0.0), gh((size_t)std::max(mtot, 1), 0.0);
+        for (int64_t i = 0; i < me; ++i) gh[i] = bh[i];
+        for (int64_t i = 0; i < mi; ++i) gh[me + i] = dh[i];
+        static const int64_t dummy_i[1] = {0}; static const double dummy_d[1] = {0.0};
+        ss.reset(new SparseSolver<T>(dev, n, mtot, dt, P0cp.data(), P0ri.empty() ? dummy_i : P0ri.data(), Pnz, Gcp.data(), Gri.empty() ? dummy_i : Gri.data(),
+                                     Gnz.empty() ? dummy_d : Gnz.data(), qh, zeros.data(), zeros.data(), 0));
+        st = ss->st;
+        const int64_t nn = n + 64, mm = mtot + 64;
+        g = dalloc<T>(mm, st); dual = dalloc<T>(mm, st); slack = dalloc<T>(mm, st); hvec = dalloc<T>(mm, st); v = dalloc<T>(mm, st); de = dalloc<T>(mm, st); di = dalloc<T>(mm, st);
+        r2 = dalloc<T>(mm, st); dnu = dalloc<T>(mm, st); zero_m = dalloc<T>(mm, st);
+        x = dalloc<T>(nn, st); xx = dalloc<T>(nn, st); X1 = dalloc<T>(nn, st); X2 = dalloc<T>(nn, st); X3 = dalloc<T>(nn, st); r1 = dalloc<T>(nn, st); dx = dalloc<T>(nn, st);
+        slots = dalloc<unsigned long long>(16, st);
+        slots_host = reinterpret_cast<unsigned long long*>(ss->res.pinned);
+        ss->upload_vec(gh.data(), g, mtot);
+        SparseSolver<T>::canonical_csc((int)n, P0cp.data(), P0ri.empty() ? dummy_i : P0ri.data(), Pnz, 0, kPcp, kPri, kPnz);
+        if (me > 0) SparseSolver<T>::canonical_csc((int)n, Acp, Ari, Anz, base, kAcp, kAri, kAnz);
+        else kAcp.assign(n + 1, 0);
+    }
+    ~SparseProxQpSolver() override {
+        (void)hipSetDevice(device);
+        if (st) (void)hipStreamSynchronize(st);
+        void* ptrs[] = {g, dual, slack, hvec, x, xx, v, de, di, X1, X2, X3, r1, r2, dx, dnu, zero_m, slots};
+        for (void* p_ : ptrs) if (p_) (void)hipFree(p_);
+    }
+    void drop_init_copies() {
+        for (auto* vv : {&kPcp, &kPri, &kAcp, &kAri}) std::vector<int64_t>().swap(*vv);
+        std::vector<double>().swap(kPnz); std::vector<double>().swap(kAnz);
+    }
+    void set_state(const double* xh, const double* yh, const double* zh, const double* sh) override {
+        HIPC(hipSetDevice(device));
+        ss->upload_vec(xh, x, n); ss->upload_vec(yh, dual, me); ss->upload_vec(zh, dual + me, mi);
+        HIPC(hipMemsetAsync(slack, 0, sizeof(T) * (size_t)(mtot + 64), st));
+        ss->upload_vec(sh, slack + me, mi);
+    }
+    void get_state(double* xh, double* yh, double* zh, double* sh) override {
+        HIPC(hipSetDevice(device));
+        if (xh) ss->download_vec(x, xh, n);
+        if (yh) ss->download_vec(dual, yh, me);
+        if (zh) ss->download_vec(dual + me, zh, mi);
+        if (sh) ss->download_vec(slack + me, sh, mi);
+    }
+    void axpby(int64_t c, T a, const T* xa, T b, const T* ya, T* out) { if (c > 0) hipLaunchKernelGGL((k_axpby<T>), g1(c), dim3(256), 0, st, (int)c, a, xa, b, ya, out); }
+
+    // ProxQP.jl:95-115: [P A'; A 0] [x; y] = [-q; b], s = max(d - C x, 0), z = 0
+    void init_kkt() override {
+        HIPC(hipSetDevice(device));
+        if (kPcp.empty()) throw QpsError(QPS_ERR_BAD_ARGUMENT, "qps_proxqp_init_kkt: the initialisation data of this handle was released (call it once, before set_state)");
+        const double delta = sizeof(T) == 8 ? 1e-8 : 1e-3;
+        LdlSymbolic sym;
+        try { sym = ldl_analyze((int)n, (int)me, kPcp.data(), kPri.data(), kAcp.data(), kAri.data(), 0, 8192, 64, 4096); }
+        catch (const std::runtime_error& e) { throw QpsError(QPS_ERR_UNSUPPORTED, e.what()); }
+        std::unique_ptr<SparseLdl<T>> kkt = make_sparse_ldl<T>(st, std::move(sym), kPnz.data(), (int64_t)kPnz.size(), kAnz.data(), (int64_t)kAnz.size());
+        kkt->factorize(1.0 / delta, 0.0);                                                          // [P A'; A -delta I]: P must be positive definite, as the reference requires
+        HIPC(hipMemsetAsync(x, 0, sizeof(T) * (size_t)(n + 64), st));
+        HIPC(hipMemsetAsync(dual, 0, sizeof(T) * (size_t)(mtot + 64), st));
+        HIPC(hipMemsetAsync(de, 0, sizeof(T) * (size_t)(mtot + 64), st));
+        const int refinements = sizeof(T) == 8 ? 4 : 6;
+        for (int it = 0; it <= refinements; ++it) {
+            // residual of the UNPERTURBED system: r1 = -q - P x - A'y, r2 = b - A x (the rows of C carry zeros in `de`, so G'de = A'y)
+            ss->spmv(ss->P, x, r1, T(-1), ss->q, T(-1), nullptr, T(0), nullptr);
+            if (me > 0) {
+                HIPC(hipMemcpyAsync(de, dual, sizeof(T) * (size_t)me, hipMemcpyDeviceToDevice, st));
+                ss->spmv(ss->At, de, r1, T(-1), r1, T(1), nullptr, T(0), nullptr);
+                ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                axpby(me, T(1), g, T(-1), v, r2);
+            }
+            kkt->solve_raw(r1, r2, dx, dnu);
+            axpby(n, T(1), x, T(1), dx, x);
+            axpby(me, T(1), dual, T(1), dnu, dual);
+        }
+        if (mtot > 0) {
+            ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);                    // G x
+            hipLaunchKernelGGL((pqrows::k_pq_init_s<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, v, dual, slack);   // :110-111
+        }
+        HIPC(hipStreamSynchronize(st));
+        drop_init_copies();
+    }
+
+    void solve(const qps_proxqp_params& p, qps_proxqp_report* rep) override {
+        HIPC(hipSetDevice(device));
+        drop_init_copies();
+        double rho = p.rho; const double sigma = p.sigma;
+        int converged = 0, conv_it = p.numIterations; double resP = INFINITY, resD = INFINITY, rho_rep = p.rho;
+        ss->ldl_prepare(rho, sigma, true);                                                          // UpdateDecomposition! (ProxQP.jl:131, :201-206)
+        for (int ii = 1; ii <= p.numIterations; ++ii) {                                             // :135
+            const bool check = (ii % p.numItrConv == 0);
+            if (mtot > 0) hipLaunchKernelGGL((pqrows::k_pq_h<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, slack, hvec);
+            ss->ldl->solve(x, ss->q, hvec, dual, rho, sigma, xx, v);                                // CalculateRhs! + UpdateX! (:208-225); v = G x
+            std::swap(x, xx);
+            if (mtot > 0) hipLaunchKernelGGL((pqrows::k_pq_update<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, v, dual, slack, (T)rho);   // :227-249
+            if (check) {                                                                            // :151  CheckConvergence! :252-298
+                ss->spmv(ss->P, x, X1, T(1), nullptr, T(0), nullptr, T(0), nullptr);                // :261
+                HIPC(hipMemsetAsync(X2, 0, sizeof(T) * (size_t)n, st)); HIPC(hipMemsetAsync(X3, 0, sizeof(T) * (size_t)n, st));
+                if (mtot > 0) {
+                    hipLaunchKernelGGL((pqrows::k_pq_split<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, dual, de, di);
+                    ss->spmv(ss->At, de, X2, T(1), nullptr, T(0), nullptr, T(0), nullptr);          // A'y (:262)
+                    ss->spmv(ss->At, di, X3, T(1), nullptr, T(0), nullptr, T(0), nullptr);          // C'z (:263)
+                }
+                HIPC(hipMemsetAsync(slots, 0, 16 * sizeof(unsigned long long), st));
+                hipLaunchKernelGGL((pqrows::k_pq_norms<T>), dim3(64), dim3(256), 0, st, (int)n, (int)me, mtot, v, g, slack, X1, X2, X3, ss->q, slots);
+                HIPC(hipMemcpyAsync(slots_host, slots, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                HIPC(hipStreamSynchronize(st));
+                const pqrows::CheckOutcome co = pqrows::decide(slots_host, p, rho);                 // :266-294
+                rho = co.rho; converged = co.converged ? 1 : 0; resP = co.resPrim; resD = co.resDual;
+                if (converged) conv_it = ii;                                                        // :155-157 (no break)
+                if (co.updated) { ss->ldl_prepare(rho, sigma, true); rho_rep = rho; }               // :159-165: UpdateM! + pattern-reusing cholesky!
+            }
+        }
+        HIPC(hipStreamSynchronize(st));
+        if (rep) { rep->converged = converged; rep->iterations = conv_it; rep->rho = rho_rep; rep->sigma = sigma; rep->resPrim = resP; rep->resDual = resD; }
+    }
+};
+
 }  // namespace
+
+ProxQpBase* make_proxqp_sparse(int device, int64_t n, int64_t me, int64_t mi, int dtype, const int64_t* Pcp, const int64_t* Pri, const double* Pnz, const double* q,
+                               const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* b, const int64_t* Ccp, const int64_t* Cri, const double* Cnz,
+                               const double* d, int index_base) {
+    if (dtype == QPS_F64) return new SparseProxQpSolver<double>(device, n, me, mi, dtype, Pcp, Pri, Pnz, q, Acp, Ari, Anz, b, Ccp, Cri, Cnz, d, index_base);
+    return new SparseProxQpSolver<float>(device, n, me, mi, dtype, Pcp, Pri, Pnz, q, Acp, Ari, Anz, b, Ccp, Cri, Cnz, d, index_base);
+}
 
 SolverBase* make_sparse_solver(int device, int64_t n, int64_t m, int dtype, const int64_t* Pcp, const int64_t* Pri,
                                const double* Pnz, const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* q,

@@ -271,6 +271,10 @@ template <typename T> struct DenseSolver : SolverBase {
         }
         if (fac_premul) {
             // blocked substitution, one launch per sweep: n / nb dependent phases handed from workgroup to workgroup inside the launch
+            if (sweep_epoch >= 0xfffffff0u) {   // the granule tags are 32-bit launch counters: start over on a cleared buffer
+                HIPC(hipMemsetAsync(pub, 0, sizeof(unsigned long long) * (size_t)trsv_blocked_pub_words<T>(NP), st));
+                sweep_epoch = 0;
+            }
             { ProfLaunchScope ps(prof, cat_fwd, sample_lvl(13)); trsv_blocked<T>(st, false, S, NP, NP, nb, tt, yv, pub, ++sweep_epoch, abort_dev); }
             { ProfLaunchScope ps(prof, cat_bwd, sample_lvl(21)); trsv_blocked<T>(st, true, S, NP, NP, nb, yv, xx, pub, ++sweep_epoch, abort_dev); }
             return;
@@ -1182,38 +1186,57 @@ QPS_API int32_t qps_proxqp_create_dense(int64_t n, int64_t me, int64_t mi, const
     *out = reinterpret_cast<qps_handle>(h);
     return QPS_OK;
 }
-// SparseProxQP (ProxQP.jl:71, :95-115): the CSC fields of the three SparseMatrixCSC inputs.  The matrices are densified and take the dense
-// path: M = P + sigma I + rho (A'A + C'C) is factorised as a dense matrix and re-factorised in place on a rho change (ProxQP.jl:193-199),
-// which stands in for the pattern-reusing sparse cholesky! of :201-206 (and makes GetNzvalDiagIdxs / AlignSparsePattern, :335-372, moot).
+// SparseProxQP (ProxQP.jl:71, :95-115): the CSC fields of the three SparseMatrixCSC inputs, kept sparse.  The linear system of UpdateX! is solved
+// in its KKT form by the sparse L D L' plugin (k_sparse.hip: SparseProxQpSolver): symbolic analysis once, a rho update re-factorises numerically
+// on the frozen pattern -- the role of AlignSparsePattern / GetNzvalDiagIdxs / UpdateM! / the pattern-reusing cholesky! (:184-190, :201-206, :335-372).
+// QPS_PROXQP_SPARSE=0 densifies the inputs onto the dense solver instead (in-place dense re-factorisation, :193-199).
 QPS_API int32_t qps_proxqp_create_csc(int64_t n, int64_t me, int64_t mi, const int64_t* Pcp, const int64_t* Pri, const double* Pnz, const double* q,
                                       const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* b, const int64_t* Ccp, const int64_t* Cri,
                                       const double* Cnz, const double* d, int32_t index_base, int32_t dtype, int32_t device, qps_handle* out) {
     if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");
     *out = nullptr;
     if (n <= 0 || me < 0 || mi < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need n >= 1, numEq >= 0, numInEq >= 0");
-    if (n > (1 << 16) || me + mi > (1 << 20)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "problem too large to densify");
     if (!Pcp || !q || (me > 0 && (!Acp || !b)) || (mi > 0 && (!Ccp || !d))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
     if (index_base != 0 && index_base != 1) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "index_base must be 0 or 1");
-    std::vector<double> Pd, Ad, Cd;
-    auto densify = [&](const int64_t* cp, const int64_t* ri, const double* nz, int64_t rows, std::vector<double>& D, const char* name) -> int {
-        D.assign((size_t)std::max<int64_t>(rows, 1) * n, 0.0);
+    if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
+    auto validate = [&](const int64_t* cp, const int64_t* ri, const double* nz, int64_t rows, const char* name) -> int {
         if (rows == 0) return QPS_OK;
         if (cp[0] != index_base) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, std::string(name) + ": colptr does not start at index_base");
-        for (int64_t j = 0; j < n; ++j) {
-            if (cp[j + 1] < cp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, std::string(name) + ": colptr not monotone");
-            for (int64_t k = cp[j] - index_base; k < cp[j + 1] - index_base; ++k) {
-                const int64_t i = ri[k] - index_base;
-                if (i < 0 || i >= rows) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, std::string(name) + ": row index out of range");
-                D[(size_t)i + (size_t)j * rows] += nz[k];
-            }
+        for (int64_t j = 0; j < n; ++j) if (cp[j + 1] < cp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, std::string(name) + ": colptr not monotone");
+        const int64_t nnz = cp[n] - index_base;
+        if (nnz > 0 && (!ri || !nz)) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, std::string(name) + ": NULL index / value array");
+        for (int64_t k = 0; k < nnz; ++k) {
+            const int64_t i = ri[k] - index_base;
+            if (i < 0 || i >= rows) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, std::string(name) + ": row index out of range");
         }
+        if (!all_finite(nz, nnz, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, std::string(name) + " contains NaN/Inf");
         return QPS_OK;
     };
-    int rc = guarded(nullptr, [&] {
-        int r = densify(Pcp, Pri, Pnz, n, Pd, "mP"); if (r == QPS_OK) r = densify(Acp, Ari, Anz, me, Ad, "mA"); if (r == QPS_OK) r = densify(Ccp, Cri, Cnz, mi, Cd, "mC");
-        if (r != QPS_OK) throw QpsError(r, g_last_error);
-    });
-    if (rc != QPS_OK) return rc;
+    int rv = validate(Pcp, Pri, Pnz, n, "mP"); if (rv == QPS_OK) rv = validate(Acp, Ari, Anz, me, "mA"); if (rv == QPS_OK) rv = validate(Ccp, Cri, Cnz, mi, "mC");
+    if (rv != QPS_OK) return rv;
+    static const bool keep_sparse = [] { const char* e = getenv("QPS_PROXQP_SPARSE"); return !(e && atoi(e) == 0); }();
+    if (keep_sparse && me + mi > 0) {
+        if (n > 2000000000LL || me + mi > 2000000000LL) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "problem too large");
+        if (!all_finite(q, n, false) || (me > 0 && !all_finite(b, me, false)) || (mi > 0 && !all_finite(d, mi, false)))
+            return fail_with(nullptr, QPS_ERR_NOT_FINITE, "q/b/d contain NaN/Inf");
+        int dc = check_device(device);
+        if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+        if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range");
+        Handle* h = new Handle(); h->n = n; h->m = me + mi;
+        int rc = guarded(nullptr, [&] { h->proxqp = make_proxqp_sparse(device, n, me, mi, dtype, Pcp, Pri, Pnz, q, Acp, Ari, Anz, b, Ccp, Cri, Cnz, d, index_base); });
+        if (rc != QPS_OK) { delete h; return rc; }
+        *out = reinterpret_cast<qps_handle>(h);
+        return QPS_OK;
+    }
+    if (n > (1 << 16) || me + mi > (1 << 20)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "problem too large to densify");
+    std::vector<double> Pd, Ad, Cd;
+    auto densify = [&](const int64_t* cp, const int64_t* ri, const double* nz, int64_t rows, std::vector<double>& D) {
+        D.assign((size_t)std::max<int64_t>(rows, 1) * n, 0.0);
+        if (rows == 0) return;
+        for (int64_t j = 0; j < n; ++j)
+            for (int64_t k = cp[j] - index_base; k < cp[j + 1] - index_base; ++k) D[(size_t)(ri[k] - index_base) + (size_t)j * rows] += nz[k];
+    };
+    densify(Pcp, Pri, Pnz, n, Pd); densify(Acp, Ari, Anz, me, Ad); densify(Ccp, Cri, Cnz, mi, Cd);
     return qps_proxqp_create_dense(n, me, mi, Pd.data(), n, q, me > 0 ? Ad.data() : nullptr, std::max<int64_t>(me, 1), b, mi > 0 ? Cd.data() : nullptr,
                                    std::max<int64_t>(mi, 1), d, dtype, device, out);
 }

@@ -20,6 +20,9 @@ template <typename T> struct SparseLdl {
     // two launches fewer per iteration than solve() + admm_update.  rhs_ready: the previous call of iterate() with the same
     // (rho, sigma) already left the right-hand side in place.
     virtual void iterate(T* x, T* xp, const T* q, T* z, T* zp, T* y, const T* l, const T* u, double alpha, double rho, double sigma, bool rhs_ready) = 0;
+    // K(rho, sigma) [out_x; out_nu] = [r1; r2] with the factor of the last factorize(): the multiplier block comes back as it is
+    // (solve() folds it into z~ = z + (nu - y) / rho, which loses nu when rho is huge)
+    virtual void solve_raw(const T* r1, const T* r2, T* out_x, T* out_nu) = 0;
     virtual const LdlSymbolic& symbolic() const = 0;
     virtual int launches_per_solve() const = 0;
     virtual double bytes_per_solve() const = 0;

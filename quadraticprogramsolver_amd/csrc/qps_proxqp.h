@@ -20,4 +20,9 @@ struct ProxQpBase {
 ProxQpBase* make_proxqp(int device, int64_t n, int64_t me, int64_t mi, int dtype, const double* P, int64_t ldp, const double* A, int64_t lda,
                         const double* b, const double* C, int64_t ldc, const double* d, const double* q);
 
+// SparseProxQP (ProxQP.jl:71, :95-115): CSC inputs kept sparse, the linear system solved in its KKT form by the sparse L D L' plugin (k_sparse.hip)
+ProxQpBase* make_proxqp_sparse(int device, int64_t n, int64_t me, int64_t mi, int dtype, const int64_t* Pcp, const int64_t* Pri, const double* Pnz, const double* q,
+                               const int64_t* Acp, const int64_t* Ari, const double* Anz, const double* b, const int64_t* Ccp, const int64_t* Cri, const double* Cnz,
+                               const double* d, int index_base);
+
 }  // namespace qps
