@@ -167,6 +167,22 @@ function ProxQPHip(mP :: Matrix{Float64}, vQ :: Vector{Float64}, mA :: Matrix{Fl
     finalizer(x -> ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), x.h), s)
     return s
 end
+# SparseProxQP (ProxQP.jl:71, :95-115): the colptr / rowval / nzval fields as they are (1-based Int64); the matrices stay sparse on the device
+function ProxQPHip(mP :: SparseMatrixCSC{Float64, Int64}, vQ :: Vector{Float64}, mA :: SparseMatrixCSC{Float64, Int64}, vB :: Vector{Float64},
+                   mC :: SparseMatrixCSC{Float64, Int64}, vD :: Vector{Float64})
+    n, me, mi = size(mP, 1), size(mA, 1), size(mC, 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    vBp = isempty(vB) ? zeros(1) : vB; vDp = isempty(vD) ? zeros(1) : vD
+    GC.@preserve mP vQ mA vBp mC vDp _check(ccall((:qps_proxqp_create_csc, LIBQPS), Int32,
+        (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+        n, me, mi, mP.colptr, mP.rowval, mP.nzval, vQ, mA.colptr, mA.rowval, mA.nzval, vBp, mC.colptr, mC.rowval, mC.nzval, vDp,
+        Int32(1), Int32(0), Int32(0), h))
+    _check(ccall((:qps_proxqp_init_kkt, LIBQPS), Int32, (Ptr{Cvoid},), h[]), h[])          # ProxQP.jl:102-111 on the device
+    s = ProxQPHip{Float64}(h[], zeros(n), zeros(max(me, 1)), zeros(max(mi, 1)), zeros(max(mi, 1)), n, me, mi)
+    finalizer(x -> ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), x.h), s)
+    return s
+end
 function SolveQuadraticProgram!(sQpProb :: ProxQPHip{Float64}; numIterations = 2000, ϵAbs = 1e-7, ϵRel = 1e-6, numItrConv = 50,
                                 ρ = 1e2, σ = 1e-2, adptΡ :: Bool = true, τ = 10.0)
     prm = QpsProxQpParams(numIterations, numItrConv, adptΡ, 0, ϵAbs, ϵRel, ρ, σ, τ)
