@@ -121,9 +121,10 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const T* __restrict__ S, int6
     *reinterpret_cast<V*>(part + (int64_t)rt * part_ld + c) = o;
 }
 
-// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  A workgroup owns 16 consecutive columns (one 128-B line per slab
-// row for fp64); CL lanes cover the line with 16-B loads and the other 256/CL lane groups walk the slabs, 8 loads in
-// flight per thread, so 256 slabs are consumed in one memory round trip.
+// out[c] = s0*a0[c] + s1*a1[c] + sum_t part[t][c].  A workgroup owns the columns of ONE 128-B line per slab row (16 fp64 / 32 fp32
+// columns; with 16 fp32 columns every slab row was a half-line read: 6.1 against 4.3 us for the same slab count); 8 lanes cover the
+// line with 16-B loads and the other 32 lane groups walk the slabs, 8 loads in flight per thread, so 256 slabs are consumed in one
+// memory round trip.
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int64_t part_ld, int ntiles,
                                                 const T* __restrict__ a0, T s0, const T* __restrict__ a1, T s1,
@@ -134,10 +135,11 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int6
     part += (int64_t)blockIdx.y * bs.mat; out += (int64_t)blockIdx.y * bs.vout;
     if (a0) a0 += (int64_t)blockIdx.y * bs.vin;
     if (a1) a1 += (int64_t)blockIdx.y * bs.vin;
-    constexpr int CL = 16 / VN;          // lanes per 16-column group
-    constexpr int TL = 256 / CL;         // slab lanes
+    constexpr int COLS = 128 / (int)sizeof(T);   // columns per workgroup: one cache line of every slab row
+    constexpr int CL = COLS / VN;        // lanes per line (8)
+    constexpr int TL = 256 / CL;         // slab lanes (32)
     const int cl = threadIdx.x % CL, tl = threadIdx.x / CL;
-    const int c = blockIdx.x * 16 + cl * VN;
+    const int c = blockIdx.x * COLS + cl * VN;
     T acc[VN];
 #pragma unroll
     for (int e = 0; e < VN; ++e) acc[e] = T(0);
@@ -161,20 +163,21 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ part, int6
             for (int e = 0; e < VN; ++e) acc[e] += vp[e];
         }
     }
-    __shared__ T red[TL][17];
+    __shared__ T red[TL][COLS + 1];
 #pragma unroll
     for (int e = 0; e < VN; ++e) red[tl][cl * VN + e] = acc[e];
     __syncthreads();
-    // 16 outputs x 16 lanes: every lane adds TL / 16 partials, a DPP row sum finishes in lane 15 of the row (fixed order -> bitwise
-    // reproducible; the serial walk over TL partials by 16 threads was ~1 us of a 4.7 us kernel)
-    static_assert(TL % 16 == 0, "slab lanes per output");
-    const int o = threadIdx.x >> 4, pl = threadIdx.x & 15;
+    // COLS outputs x PL = 256 / COLS lanes: every lane adds TL / PL partials, a DPP sum over the PL lanes finishes the column (fixed order ->
+    // bitwise reproducible; the serial walk over TL partials by 16 threads was ~1 us of a 4.7 us kernel)
+    constexpr int PL = 256 / COLS;       // 16 (fp64) / 8 (fp32)
+    static_assert(TL % PL == 0 && (PL == 16 || PL == 8), "slab lanes per output");
+    const int o = threadIdx.x / PL, pl = threadIdx.x % PL;
     T s = T(0);
 #pragma unroll
-    for (int k = 0; k < TL / 16; ++k) s += red[pl * (TL / 16) + k][o];
-    s = row16_sum_last(s);
-    const int oc = blockIdx.x * 16 + o;
-    if (pl == 15 && oc < ncols) {
+    for (int k = 0; k < TL / PL; ++k) s += red[pl * (TL / PL) + k][o];
+    s = (PL == 16) ? row16_sum_last(s) : oct_sum_all(s);
+    const int oc = blockIdx.x * COLS + o;
+    if (pl == PL - 1 && oc < ncols) {
         T r = s;
         if (a0) r += s0 * a0[oc];
         if (a1) r += s1 * a1[oc];
@@ -340,13 +343,14 @@ int gemv_cols_partial(hipStream_t st, const T* S, int64_t ld, const T* va, const
 template <typename T>
 void colsum(hipStream_t st, const T* part, int64_t part_ld, int ntiles, const T* a0, T s0, const T* a1, T s1, T* out,
             int ncols, BatchStride bs) {
+    constexpr int cols_wg = 128 / (int)sizeof(T);   // k_colsum: one cache line of every slab row per workgroup
     if (g_launch_timing.start) {   // profiled launch: the dispatch's own timestamps (qps_kernels.h)
         const LaunchTiming lt = g_launch_timing;
         g_launch_timing = LaunchTiming();
-        hipExtLaunchKernelGGL((k_colsum<T>), dim3((ncols + 15) / 16, bs.count), dim3(256), 0, st, lt.start, lt.stop, 0, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols, bs);
+        hipExtLaunchKernelGGL((k_colsum<T>), dim3((ncols + cols_wg - 1) / cols_wg, bs.count), dim3(256), 0, st, lt.start, lt.stop, 0, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols, bs);
         return;
     }
-    hipLaunchKernelGGL((k_colsum<T>), dim3((ncols + 15) / 16, bs.count), dim3(256), 0, st, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols, bs);
+    hipLaunchKernelGGL((k_colsum<T>), dim3((ncols + cols_wg - 1) / cols_wg, bs.count), dim3(256), 0, st, part, part_ld, ntiles, a0, s0, a1, s1, out, ncols, bs);
 }
 
 template <typename T>

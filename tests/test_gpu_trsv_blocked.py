@@ -160,3 +160,34 @@ def test_blocked_sweep_gives_up_cleanly(gpu, tmp_path):
             a, b = np.array(other[tag]["x"]), np.array(base[tag]["x"])
             assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), tag
         assert other["adaptive"]["iterations"] == base["adaptive"]["iterations"] and other["adaptive"]["refactor"] == base["adaptive"]["refactor"]
+
+
+def test_blocked_sweeps_from_two_host_threads(gpu, c_oracle):
+    """Two handles driven from two host threads, both on the single-launch blocked sweeps: two persistent 256-workgroup launches share the
+    chip.  Either their workgroups are resident together (the hand-offs complete) or a launch gives up after its bounded spin and the handle
+    repeats the solve on the multi-launch substitution -- both ways every solve returns the oracle's iterates."""
+    import threading
+    cases = [GenerateDenseBenchmarkQP(2100, 400, stream=60, feasible=True), GenerateDenseBenchmarkQP(2500, 300, stream=61, feasible=True)]
+    results = [None, None]
+
+    def work(k):
+        P, q, A, l, u = cases[k]
+        with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+            outs = []
+            for rep in range(4):
+                x = np.zeros(P.shape[0]); info = {}
+                prob.solve(x, numIterations=200, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, trsvBlock=1024, info=info)
+                outs.append((x, info["sweepVariant"]))
+            results[k] = outs
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for k in range(2):
+        assert results[k] is not None
+        xo, _ = c_oracle.solve(*cases[k], numIterations=200, epsAbs=0.0, epsRel=0.0, rho=0.1)
+        for x, variant in results[k]:
+            assert variant in (1, 5) and rel(x, xo) <= 1e-9
+        print("sweep variants of thread", k, [v for _, v in results[k]])
