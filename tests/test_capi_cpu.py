@@ -193,6 +193,43 @@ def test_proxqp_defaults_are_the_reference_defaults(qps):
     assert (p.numIterations, p.epsAbs, p.epsRel, p.numItrConv, p.rho, p.sigma, p.adptRho, p.tau) == (2000, 1e-7, 1e-6, 50, 1e2, 1e-2, 1, 10.0)
 
 
+def test_sparse_proxqp_constructor_validates_before_it_needs_a_device(qps):
+    """qps_proxqp_create_csc (SparseProxQP, ProxQP.jl:71, :95-115) checks the CSC fields on the host: a malformed colptr, a row index out of
+    range or a NaN is refused with its own status whether or not a GPU is visible; well-formed input without a GPU fails loudly with NO_DEVICE."""
+    import scipy.sparse as sp
+    from quadraticprogramsolver_amd import _lib
+    n, me, mi = 6, 2, 3
+    P = sp.identity(n, format="csc"); A = sp.csc_matrix(np.ones((me, n))); Cm = sp.csc_matrix(np.ones((mi, n)))
+    q, b, d = np.zeros(n), np.zeros(me), np.ones(mi)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def create(Pm=P, Am=A, Cmm=Cm, edit=None, base=0):
+        arrs = []
+        for M in (Pm, Am, Cmm):
+            arrs.append([M.indptr.astype(np.int64) + base, M.indices.astype(np.int64) + base, M.data.astype(np.float64).copy()])
+        if edit:
+            edit(arrs)
+        h = C.c_void_p()
+        (Pc, Pr, Pv), (Ac, Ar, Av), (Cc, Cr, Cv) = arrs
+        return _lib.lib().qps_proxqp_create_csc(n, me, mi, ip(Pc), ip(Pr), dp(Pv), dp(q), ip(Ac), ip(Ar), dp(Av), dp(b), ip(Cc), ip(Cr), dp(Cv), dp(d), base, 0, 0, C.byref(h)), h
+
+    def bad_colptr(a): a[1][0][2] = a[1][0][1] - 1
+    def bad_row(a): a[2][1][0] = mi + 5
+    def nan_val(a): a[0][2][0] = np.nan
+    def bad_start(a): a[0][0][0] = 1
+    assert create(edit=bad_colptr)[0] == 1      # QPS_ERR_BAD_ARGUMENT
+    assert create(edit=bad_row)[0] == 2         # QPS_ERR_BAD_DIMENSION
+    assert create(edit=nan_val)[0] == 3         # QPS_ERR_NOT_FINITE
+    assert create(edit=bad_start)[0] == 1
+    rc, h = create(base=1)                      # Julia's 1-based fields
+    if _lib.lib().qps_device_count() > 0:
+        assert rc == 0
+        _lib.lib().qps_destroy(h)
+    else:
+        assert rc == 7                          # QPS_ERR_NO_DEVICE: there is no CPU fallback
+
+
 def test_no_null_stream_fills_or_uploads_in_the_library():
     """Stream-ordering rule (qps_internal.h): handles work on non-blocking streams, so nothing their kernels read may be written
     through the null stream.  Synchronous hipMemset / hipMemcpy, waits on the null stream and device-wide synchronisations that
