@@ -1,6 +1,7 @@
 // k_trsv.hip -- the triangular solve for the case where one inverted diagonal block covers the whole factor (nb >= n):
 // both sweeps of x~ = L'^{-1} (L^{-1} t) in one pass over W = inv(L).  (A persistent, software-pipelined kernel per
 // *separate* sweep was measured and dropped: 17-20 us per sweep against 18.8 us for the plain row-dot launch.)
+#include <algorithm>
 #include <cstdlib>
 
 #include "qps_kernels.h"
@@ -135,6 +136,96 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Narrow factors (a row fits ONE wave: NP <= 64 * VN * KCW = 1024 fp64 / 2048 fp32 -- BASELINE config 4's n = 1024): a WAVE owns a row.
+// In the kernel above 512 threads share a row of at most 8 KB: one 16-byte load per thread, then a wave reduction, an LDS exchange and a
+// barrier per row pair -- on the batched n = 1024 problems that bookkeeping, not the bytes, set the pace (38 us for 134 MB).  Here every wave
+// streams whole rows (KCW 16-byte loads per lane and row, the next row in flight), the row dot ends in one DPP wave sum with no LDS traffic
+// and no barrier, the column accumulation stays in the wave's registers, and the eight waves of a workgroup add their column sums through LDS
+// once, at the end.  Rows are dealt cyclically over all waves of a QP, longest first.  Same slab interface as k_sweep_fused.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int KCW>
+__global__ __launch_bounds__(512) void k_sweep_fused_wave(const T* __restrict__ S, int64_t ld, int NP, const T* __restrict__ v,
+                                                          T* __restrict__ part, int64_t part_ld, BatchStride bs) {
+    using V = typename VecOf<T>::type;
+    constexpr int VN = VecOf<T>::N, CH = 64 * VN, WAVES = 8, COLS = KCW * CH;
+    if (bs.active && !bs.active[blockIdx.y]) return;
+    S += (int64_t)blockIdx.y * bs.mat; v += (int64_t)blockIdx.y * bs.vin; part += (int64_t)blockIdx.y * bs.vout;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    const int W = gridDim.x * WAVES, w = wave * gridDim.x + g;        // global wave index: neighbouring rows go to different workgroups
+    __shared__ T sh[WAVES][COLS];
+
+    V xv[KCW];
+    T acc[KCW][VN];
+#pragma unroll
+    for (int k = 0; k < KCW; ++k) {
+        const int c = k * CH + lane * VN;
+        xv[k] = *reinterpret_cast<const V*>(v + min(c, NP - VN));
+        if (c >= NP) { T* p = reinterpret_cast<T*>(&xv[k]);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) p[e] = T(0); }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[k][e] = T(0);
+    }
+    auto row_of = [&](int it) { return NP - 1 - (w + it * W); };
+    auto load = [&](V (&a)[KCW], int r) {
+#pragma unroll
+        for (int k = 0; k < KCW; ++k) {
+            // unconditional loads (exact load counting): lanes right of the diagonal re-read the diagonal's own vector -- a line the row needs anyway
+            const int c = k * CH + lane * VN;
+            const int cc = min(min(c, r & ~(VN - 1)), NP - VN);
+            a[k] = *reinterpret_cast<const V*>(S + (int64_t)r * ld + cc);
+        }
+    };
+    auto process = [&](V (&a)[KCW], int r) {
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k < KCW; ++k) {
+            const int c = k * CH + lane * VN;
+            T* ap = reinterpret_cast<T*>(&a[k]);
+            const T* xp = reinterpret_cast<const T*>(&xv[k]);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                if (c + e > r) ap[e] = T(0);                       // entries above the diagonal belong to the mirrored half
+                s += ap[e] * xp[e];
+            }
+        }
+        const T y = wave_sum_all(s);                               // y_r = W_r . t
+#pragma unroll
+        for (int k = 0; k < KCW; ++k) {
+            const T* ap = reinterpret_cast<const T*>(&a[k]);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[k][e] += ap[e] * y;   // x~ += W_r' y_r
+        }
+    };
+    const int mine = w < NP ? (NP - w + W - 1) / W : 0;
+    if (mine > 0) {
+        V bufA[KCW], bufB[KCW];
+        load(bufA, row_of(0));
+        for (int it = 0; it < mine; it += 2) {
+            const int rb = row_of(min(it + 1, mine - 1));          // past the end: the last row again, never used
+            load(bufB, rb);
+            process(bufA, row_of(it));
+            load(bufA, row_of(min(it + 2, mine - 1)));
+            if (it + 1 < mine) process(bufB, rb);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KCW; ++k)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) sh[wave][k * CH + lane * VN + e] = acc[k][e];
+    __syncthreads();
+    for (int c = tid; c < NP; c += 512) {
+        T t = T(0);
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) t += sh[q][c];                 // fixed order
+        part[(int64_t)g * part_ld + c] = t;
+    }
+}
+
+static bool sweep_wave() { static const bool on = [] { const char* e = getenv("QPS_SWEEP_WAVE"); return !(e && atoi(e) == 0); }(); return on; }
+template <typename T> static bool sweep_wave_covers(int NP) { return sweep_wave() && NP <= 64 * VecOf<T>::N * 8; }
+
 }  // namespace
 
 template <typename T> bool sweep_fused_supported(int NP) { return NP <= 16 * 512 * VecOf<T>::N && NP >= 1024; }   // 16384 fp64 / 32768 fp32
@@ -142,6 +233,10 @@ template <typename T> bool sweep_fused_supported(int NP) { return NP <= 16 * 512
 static int sweep_rb() { static int rb = [] { const char* e = getenv("QPS_SWEEP_RB"); return e ? atoi(e) : 2; }(); return rb; }   // fp64: 2-row tiles measured best
 
 template <typename T> int sweep_fused_slabs(int NP, int count) {
+    if (sweep_wave_covers<T>(NP)) {      // wave-per-row kernel: about one workgroup per CU over the whole launch, at least two rows per wave
+        const int per = count >= 256 ? 1 : 256 / (count < 1 ? 1 : count);
+        return std::max(1, std::min(per, NP / 16));
+    }
     int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
     if (NP > 8 * 512 * VecOf<T>::N) RB = 1;   // wide single-buffered variants
     static const int total_env = [] { const char* e = getenv("QPS_SWEEP_WGS"); return e ? atoi(e) : 0; }();
@@ -163,6 +258,16 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
     const bool rb2 = (sweep_rb() == 2 && VecOf<T>::N == 2);
     const LaunchTiming lt = g_launch_timing;   // profiled launch: the dispatch's own timestamps (qps_kernels.h)
     g_launch_timing = LaunchTiming();
+    if (sweep_wave_covers<T>(NP)) {
+#define QPS_WV(KCW)                                                                                                                \
+    do {                                                                                                                           \
+        if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused_wave<T, KCW>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \
+        else hipLaunchKernelGGL((k_sweep_fused_wave<T, KCW>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs);              \
+    } while (0)
+        if (NP <= 64 * VecOf<T>::N * 4) QPS_WV(4); else QPS_WV(8);
+#undef QPS_WV
+        return G;
+    }
 #define QPS_S(KC, RB)                                                                                                              \
     do {                                                                                                                           \
         if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused<T, TH, KC, RB>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \

@@ -607,7 +607,7 @@ def test_register_resident_single_launch_kernel(gpu, c_oracle, dtype, n, m):
 
 KNOBS = [{"QPS_GRAPH": "0"}, {"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
          {"QPS_SMALL_REG": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"},
-         {"QPS_CHOL_STEP": "64"}]
+         {"QPS_CHOL_STEP": "64"}, {"QPS_SWEEP_WAVE": "0"}]
 
 
 @pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -621,7 +621,7 @@ def test_tuning_knobs_do_not_change_results(gpu, knob, tmp_path):
         sys.path.insert(0, sys.argv[1])
         import quadraticprogramsolver_amd as q
         out = {}
-        for tag, (n, m) in {"small": (64, 128), "mid": (1100, 2300)}.items():
+        for tag, (n, m) in {"small": (64, 128), "mid": (1100, 2300), "narrow": (1000, 700)}.items():
             P, qq, A, l, u = q.GenerateDenseBenchmarkQP(n, m, stream=7, feasible=True)
             x = np.zeros(n); q.SolveQuadraticProgramInplace(x, P, qq, A, l, u, numIterations=60, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
             out[tag] = x.tolist()
