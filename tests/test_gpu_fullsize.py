@@ -244,3 +244,28 @@ def test_explicit_inverse_sweep_vs_substitution_at_extreme_rho(gpu, c2_problem):
     d = [rel(out[64][k], out[4096][k]) for k in range(3)]
     note(f"(c) n=4096 rho=1e6, 50 iterations: x / z / y of nb=64 vs nb=4096 differ by {d[0]:.3e} / {d[1]:.3e} / {d[2]:.3e} (relative)")
     assert d[0] <= 1e-9 and d[1] <= 1e-9 and d[2] <= 1e-8
+
+
+def test_matlab_unit_test_configuration(gpu, c_oracle):
+    """SolveQuadraticProgramUnitTest.m:50-63, :90-100: isotonicRegression, numElements = 1000, 5000 iterations, eps = 1e-9, paramRho = 1e6 with
+    adaptRho, the iterative linear-solver mode (here: the matrix-free CG plugin; MATLAB's pcg), 10 polishing iterations -- and, as the script
+    prints them, the objective value and the constraint violations.  Reference = the CPU oracle with the same parameters (quadprog / CVX are absent);
+    the direct plugins (sparse L D L' and the dense reduced form) must land on the same point."""
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.isotonicRegression, 1000, rng=make_rng(1234, 800))
+    n = P.shape[0]
+    Pd = P.toarray() if sp.issparse(P) else np.asarray(P)
+    Ad = A.toarray() if sp.issparse(A) else np.asarray(A)
+    obj = lambda x: 0.5 * x @ (Pd @ x) + q @ x
+    kw = dict(numIterations=5000, ϵAbs=1e-9, ϵRel=1e-9, ρ=1e6, adptΡ=True, numItrConv=50)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=5000, epsAbs=1e-9, epsRel=1e-9, rho=1e6, adptRho=True, numItrConv=50,
+                            linsys=c_oracle.KIND_CG_MATFREE)
+    got = {}
+    for name, pair in (("cg", (gpu.HipCgInit, gpu.HipCg)), ("ldl", (gpu.HipLdlInit, gpu.HipLdl)), ("chol", (gpu.HipCholInit, gpu.HipChol))):
+        x = np.zeros(n); info = {}
+        flag = gpu.SolveQuadraticProgramInplace(x, P, q, A, l, u, *pair, info=info, polish=True, numItrPolish=10, **kw)
+        Ax = Ad @ x
+        assert np.abs(x - xo).max() <= ABS_DEV_THR, name
+        assert abs(obj(x) - obj(xo)) <= 1e-7 * max(1.0, abs(obj(xo))), name
+        assert (Ax - l).min() >= -1e-6 and (Ax - u).max() <= 1e-6, name          # "L Violation" / "U Violation" of the script
+        got[name] = (int(flag), info["iterations"])
+    assert got["cg"][0] == io["convFlag"]
