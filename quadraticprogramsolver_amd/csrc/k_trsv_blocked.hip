@@ -22,8 +22,9 @@
 //     LDS and raises the LDS flag the streaming waves wait on before their last tile of the block row.
 // The epoch is a per-launch argument that only ever grows, so no word has to be cleared between launches and a launch that gave up
 // leaves nothing behind.  Every spin is bounded: a courier that waited `spin_limit` polls sets `abort_word`, every courier checks that word
-// while it spins, and the launch drains with garbage in `out`; the host sees the word at its next read-back, re-factorises for the
-// explicit-inverse sweep and repeats the solve (qps_capi.hip).
+// while it spins, and the launch drains with garbage in `out`; the host sees the word at its next read-back, rebuilds the plain (not
+// pre-multiplied) sweep matrix, repeats the solve on the one-launch-per-phase substitution and keeps the handle there (qps_capi.hip).
+// Seen in practice when two handles run these launches at the same time from two host threads (tests/test_gpu_trsv_blocked.py).
 #include <cstdlib>
 
 #include "qps_kernels.h"
