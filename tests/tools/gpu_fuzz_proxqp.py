@@ -1,0 +1,43 @@
+"""Randomised differential run of the ProxQP form (dense and sparse solver) against the numpy restatement (not a test).
+usage: python tests/tools/gpu_fuzz_proxqp.py [cases] [seed]"""
+import sys, os, time
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np, scipy.sparse as sp
+import quadraticprogramsolver_amd as q
+from oracle import proxqp_oracle_np as po
+from test_gpu_proxqp import make_problem, make_sparse_problem, rel
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+bad = 0; t0 = time.time()
+for c in range(cases):
+    sparse = bool(rng.random() < 0.5)
+    n = int(rng.choice([5, 40, 64, 130, 300, 700])); me = int(rng.choice([0, 1, n // 4, n // 2])); mi = int(rng.choice([0, 3, n, 2 * n]))
+    if me + mi == 0: mi = 7
+    adpt = bool(rng.random() < 0.6); K = int(rng.choice([50, 150, 400])); rho = float(rng.choice([1.0, 50.0, 200.0])); nic = int(rng.choice([10, 50]))
+    feas = bool(rng.random() < 0.7); explicit = bool(rng.random() < 0.5)
+    tag = f"case {c}: {'sparse' if sparse else 'dense'} n={n} me={me} mi={mi} K={K} adpt={adpt} rho={rho} numItrConv={nic} feasible={feas} explicit_state={explicit}"
+    try:
+        if sparse:
+            P, qv, A, b, C, d = make_sparse_problem(n, me, mi, 500 + c, density=min(0.3, 8.0 / n), feasible=feas)
+            Pd, Ad, Cd = P.toarray(), A.toarray(), C.toarray()
+        else:
+            P, qv, A, b, C, d = make_problem(n, me, mi, 500 + c, feas); Pd, Ad, Cd = P, A, C
+        ref = po.ProxQP.from_problem(Pd, qv, Ad, b, Cd, d)
+        init = po.ProxQP.from_problem(Pd, qv, Ad, b, Cd, d)
+        rr = po.SolveQuadraticProgramProxQP(ref, numIterations=K, ρ=rho, σ=1e-2, adptΡ=adpt, τ=10.0, numItrConv=nic)
+        args = (P, qv, A, b, C, d) + ((init.vX, init.vY, init.vZ, init.vS) if explicit else ())
+        with q.ProxQP(*args) as prob:
+            d0 = max(rel(prob.vX, init.vX), rel(prob.vY, init.vY) if me else 0.0)
+            rg = q.SolveQuadraticProgramProxQP(prob, numIterations=K, ρ=rho, σ=1e-2, adptΡ=adpt, τ=10.0, numItrConv=nic)
+            dev = max(rel(prob.vX, ref.vX), rel(prob.vZ, ref.vZ) if mi else 0.0, rel(prob.vS, ref.vS) if mi else 0.0)
+            # (once both residuals sit at rounding level the rho update is driven by a ratio of rounding noise: not comparable)
+            noise = max(rr["PrimalResidual"], rr["DualResidual"]) < 1e-9
+            same = rg["Converged"] == rr["Converged"] and rg["Iterations"] == rr["Iterations"] and (noise or abs(rg["ρ"] - rr["ρ"]) <= 1e-8 * rr["ρ"])
+        if not (d0 <= 1e-7 and dev <= 1e-6 and same):
+            bad += 1; print(f"MISMATCH {tag}: init {d0:.1e} dev {dev:.1e} report {rg} vs {rr}", flush=True)
+        else:
+            print(f"ok {tag}: init {d0:.1e} dev {dev:.1e}", flush=True)
+    except Exception as e:
+        bad += 1; print(f"ERROR {tag}: {type(e).__name__}: {e}", flush=True)
+print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
