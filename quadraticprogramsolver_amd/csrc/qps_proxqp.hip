@@ -120,7 +120,8 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
             if (r0 > 0) gemv_rows<T>(st, Sm, NPm, out, work, work, T(-1), T(1), 0, r0, r0, r1, 0);
         }
     }
-    int pick(int NPm) { int p = 64; while (p < NPm && p < 4096) p *= 2; return p; }
+    // one inverted block over the whole factor while the fused forward+backward sweep covers it (as DenseSolver does), else 4096-blocks
+    int pick(int NPm) { const int cap = sweep_fused_supported<T>(NPm) ? 32768 : 4096; int p = 64; while (p < NPm && p < cap) p *= 2; return p; }
 
     // UpdateDecomposition! (ProxQP.jl:193-199): M = P + rho K + sigma I, Cholesky, sweep matrix
     void update_decomposition(double rho, double sigma) {
@@ -161,7 +162,7 @@ template <typename T> struct ProxQpSolver : ProxQpBase {
         check_fail("P (KKT initialisation)");
         HIPC(hipMemsetAsync(dual, 0, sizeof(T) * MP, st));
         if (me > 0) {
-            if (nbP < NP) throw QpsError(QPS_ERR_UNSUPPORTED, "KKT initialisation on the device needs n <= 4096 (pass an explicit state instead)");
+            if (nbP < NP) throw QpsError(QPS_ERR_UNSUPPORTED, "KKT initialisation of the dense solver needs n <= 16384 fp64 / 32768 fp32 (pass an explicit state, or CSC inputs for the sparse solver)");
             // B = W_P A'  (NP x MEP), W_P = inv(L_P) = lower triangle of S ; Schur = B'B = A P^{-1} A'
             T* Wl = tmp;                                             // lower-only copy of the sweep matrix
             hipLaunchKernelGGL((k_pq_lower<T>), dim3((NP + 255) / 256, NP), dim3(256), 0, st, NP, S, Wl);

@@ -40,6 +40,20 @@ def test_kkt_initialisation_matches_reference_constructor(gpu, po, n, me, mi):
         assert rel(prob.vS, ref.vS) <= 1e-8 and np.all(prob.vZ == 0)
 
 
+def test_dense_solver_beyond_one_4096_block(gpu, po):
+    """n = 4500 (NP = 4544): the dense solver keeps one inverted block over the whole factor (fused sweeps) and its KKT initialisation
+    (range-space method on the explicit inverse) works past 4096."""
+    n, me, mi = 4500, 300, 500
+    P, q, A, b, C, d = make_problem(n, me, mi, 13)
+    ref = po.ProxQP.from_problem(P, q, A, b, C, d)
+    with gpu.ProxQP(P, q, A, b, C, d) as prob:
+        assert rel(prob.vX, ref.vX) <= 1e-8 and rel(prob.vY, ref.vY) <= 1e-7 and rel(prob.vS, ref.vS) <= 1e-8
+        rr = po.SolveQuadraticProgramProxQP(ref, numIterations=100, ρ=200.0, adptΡ=True)
+        rg = gpu.SolveQuadraticProgramProxQP(prob, numIterations=100, ρ=200.0, adptΡ=True)
+        assert rel(prob.vX, ref.vX) <= 1e-8 and rel(prob.vZ, ref.vZ) <= 1e-7
+        assert rg["Iterations"] == rr["Iterations"] and abs(rg["ρ"] - rr["ρ"]) <= 1e-8 * rr["ρ"]
+
+
 @pytest.mark.parametrize("n,me,mi,feasible", [(90, 30, 70, True), (90, 60, 70, False), (64, 0, 100, True), (300, 100, 400, True), (1100, 0, 1500, True)])
 @pytest.mark.parametrize("adpt", [False, True])
 @pytest.mark.parametrize("variant", [0, 1])
