@@ -183,6 +183,50 @@ struct KEntry { int row, col, src; };
 
 }  // namespace
 
+// Fallback ordering for chain-like graphs (banded KKT systems: isotonic regression, trend filtering, control problems), where minimum degree
+// peels the band from its ends and leaves an elimination tree as deep as the matrix is long -- one dependent launch per column.  The vertices are
+// laid out on a line by breadth-first search (every edge then spans at most `bw` positions), and the line is dissected recursively: the `bw`
+// positions in the middle of an interval separate its halves, the halves are ordered first (recursively; short intervals keep their line order),
+// the separator last.  Depth of the elimination tree: leaf length + bw * log2(N / leaf) instead of N.  Returns an empty vector when the line
+// order is not narrow enough for this to help (bw > N / 16).
+std::vector<int> line_dissection_order(int N, const std::vector<std::vector<int>>& adj) {
+    std::vector<int> pos(N, -1), line; line.reserve(N);
+    std::vector<int> degree_order(N);
+    for (int i = 0; i < N; ++i) degree_order[i] = i;
+    std::stable_sort(degree_order.begin(), degree_order.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+    auto bfs = [&](int start, std::vector<int>& out, std::vector<int>& mark, int stamp) {
+        out.clear(); out.push_back(start); mark[start] = stamp;
+        for (size_t h = 0; h < out.size(); ++h)
+            for (int w : adj[out[h]]) if (mark[w] != stamp && pos[w] < 0) { mark[w] = stamp; out.push_back(w); }
+    };
+    std::vector<int> mark(N, 0), comp; int stamp = 0;
+    for (int s0 : degree_order) {
+        if (pos[s0] >= 0) continue;
+        bfs(s0, comp, mark, ++stamp);                       // pseudo-peripheral start: the last vertex of a search is far from its root
+        bfs(comp.back(), comp, mark, ++stamp);
+        bfs(comp.back(), comp, mark, ++stamp);
+        for (int v : comp) { pos[v] = (int)line.size(); line.push_back(v); }
+    }
+    int bw = 1;
+    for (int v = 0; v < N; ++v) for (int w : adj[v]) bw = std::max(bw, std::abs(pos[v] - pos[w]));
+    if ((int64_t)bw * 16 > N) return std::vector<int>();
+    const int leaf = std::max(4 * bw, 128);
+    std::vector<int> order; order.reserve(N);
+    // explicit stack: (lo, hi, separator range to emit after both halves)
+    struct Item { int lo, hi, state, slo, shi; };
+    std::vector<Item> st; st.push_back({0, N, 0, 0, 0});
+    while (!st.empty()) {
+        Item it = st.back(); st.pop_back();
+        if (it.state == 1) { for (int k = it.slo; k < it.shi; ++k) order.push_back(line[k]); continue; }
+        if (it.hi - it.lo <= leaf) { for (int k = it.lo; k < it.hi; ++k) order.push_back(line[k]); continue; }
+        const int mid = it.lo + (it.hi - it.lo) / 2, slo = mid - bw / 2, shi = slo + bw;
+        st.push_back({0, 0, 1, slo, shi});                  // emitted last (popped last)
+        st.push_back({shi, it.hi, 0, 0, 0});
+        st.push_back({it.lo, slo, 0, 0, 0});
+    }
+    return order;
+}
+
 LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, const int64_t* Acp, const int64_t* Ari, int base,
                         int max_tail, int min_level_width, int max_levels) {
     LdlSymbolic S;
@@ -208,8 +252,8 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     S.nnzK = (int64_t)ent.size();
     lap("entries of K");
     // ---- ordering
+    std::vector<std::vector<int>> adj(N);
     {
-        std::vector<std::vector<int>> adj(N);
         std::vector<int> cnt(N, 0);
         for (const KEntry& e : ent) { cnt[e.row]++; cnt[e.col]++; }
         for (int i = 0; i < N; ++i) adj[i].reserve(cnt[i]);
@@ -220,6 +264,10 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
         lap("minimum-degree ordering");
     }
     std::vector<int> ip(N);
+    // ordering pass: 0 = minimum degree, 1 = line dissection on trial, 2 = final (whichever was kept)
+    int pass = 0, md_levels = 0; std::vector<int> md_perm;
+    const int dissect_from = [] { const char* e = getenv("QPS_LDL_DISSECT_LEVELS"); return e ? atoi(e) : 256; }();
+retry_with_other_ordering:
     for (int k = 0; k < N; ++k) ip[S.perm[k]] = k;
     // ---- elimination tree of the permuted matrix (Liu's algorithm with path compression on the row subtrees)
     auto lower_cols = [&](const std::vector<int>& iperm, std::vector<int>& cptr, std::vector<int>& rows) {
@@ -264,8 +312,20 @@ LdlSymbolic ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, co
     int first_tail_level = height;
     while (first_tail_level > 0 && (lcount[first_tail_level] - lcount[first_tail_level - 1]) < min_level_width && (N - lcount[first_tail_level - 1]) <= max_tail)
         --first_tail_level;
+    if (pass == 0 && first_tail_level > dissect_from) {
+        // every sparse level is a dependent launch in each triangular sweep: minimum degree left a chain (banded system) -- try the dissected
+        // breadth-first line (line_dissection_order above) and keep it when it at least halves the number of levels
+        std::vector<int> alt = line_dissection_order(N, adj);
+        lap("line dissection ordering (deep elimination tree under minimum degree)");
+        if (!alt.empty()) { pass = 1; md_levels = first_tail_level; md_perm = S.perm; S.perm.swap(alt); goto retry_with_other_ordering; }
+    }
+    if (pass == 1) {
+        pass = 2;
+        if (2 * first_tail_level > md_levels) { S.perm = md_perm; goto retry_with_other_ordering; }   // no better: back to minimum degree
+    }
     if (first_tail_level > max_levels) throw std::runtime_error("sparse KKT LDL': elimination tree too deep for the level-scheduled solves (" + std::to_string(first_tail_level) +
                                                                " sparse levels); use the CG plugin for this problem");
+    { std::vector<std::vector<int>>().swap(adj); }
     S.Ns = lcount[first_tail_level]; S.Nt = N - S.Ns;
     S.level_ptr.assign(lcount.begin(), lcount.begin() + first_tail_level + 1);
     // compose the permutations

@@ -49,6 +49,10 @@ struct LdlSymbolic {
 // Symmetric pattern as adjacency lists without self loops -> elimination order (approximate minimum degree, Amestoy / Davis / Duff).
 std::vector<int> amd_order(int N, const std::vector<std::vector<int>>& adj);
 
+// Fallback for chain-like graphs whose minimum-degree elimination tree is as deep as the matrix is long: recursive dissection of the breadth-first
+// line order (empty result: the line order is too wide for it to help).
+std::vector<int> line_dissection_order(int N, const std::vector<std::vector<int>>& adj);
+
 // P, A: CSC with 0-based 32-bit-safe indices (P full symmetric storage; only its lower triangle is read).
 // max_tail: upper bound for Nt; min_level_width: a level narrower than this goes to the tail when the tail has room.
 // Throws std::runtime_error when the factor would not fit (nnz(L) beyond 2^31 - 1 or the level count beyond max_levels).

@@ -171,6 +171,40 @@ def test_ldl_symbolic_analysis(qps, pc, n):
     assert np.array_equal(perm, perm1) and rep == rep1
 
 
+def _banded_qp(n, seed=0):
+    """Chain-structured QP (smoothing / trend-filtering shape): tridiagonal SPD P, first-difference constraints -- a banded KKT matrix."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    P = sp.diags([-np.ones(n - 1), 2.5 + rng.random(n), -np.ones(n - 1)], [-1, 0, 1], format="csc")
+    A = sp.diags([-np.ones(n - 1), np.ones(n - 1)], [0, 1], shape=(n - 1, n), format="csc")
+    return P, rng.standard_normal(n), A, -0.1 * np.ones(n - 1), 0.1 * np.ones(n - 1)
+
+
+def test_ldl_analysis_of_chain_like_problems_falls_back_to_line_dissection(qps, monkeypatch):
+    """A banded KKT matrix has a minimum-degree elimination tree about as deep as the matrix is long.  While the chain fits the dense tail
+    (<= 8192 columns) it is simply factorised densely; beyond that every level would be a dependent launch in each triangular sweep, and the
+    analysis dissects the breadth-first line order instead: still a permutation, a factor that matches an independent boolean elimination, a
+    few hundred levels where minimum degree gave thousands; same through the 1-based entry.  (The small instance runs with a 512-column tail
+    limit so that the fallback is reached at a size the boolean elimination can check.)"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("QPS_LDL_MAX_TAIL", "512")
+    P, q, A, l, u = _banded_qp(3000)
+    nn, m = P.shape[0], A.shape[0]
+    perm, rep = _analyze(P, A)
+    assert sorted(perm.tolist()) == list(range(nn + m))
+    K = sp.bmat([[sp.csc_matrix(P) + sp.eye(nn), sp.csc_matrix(A).T], [sp.csc_matrix(A), -sp.eye(m)]], format="csr")
+    assert rep["nnzL"] == _symbolic_nnz(K, perm)
+    assert rep["numRows"] == nn + m == rep["numSparseColumns"] + rep["tailSize"]
+    assert rep["treeHeight"] <= 400 and rep["numSparseLevels"] <= 400
+    perm1, rep1 = _analyze(P, A, base=1)
+    assert np.array_equal(perm, perm1) and rep == rep1
+    # a large instance analyses with the default limits too (minimum degree alone: refused, "elimination tree too deep")
+    monkeypatch.delenv("QPS_LDL_MAX_TAIL")
+    P, q, A, l, u = _banded_qp(100000, 1)
+    perm, rep = _analyze(P, A)
+    assert rep["numRows"] == 199999 and rep["numSparseLevels"] <= 600 and rep["nnzL"] <= 12 * rep["nnzK"]
+
+
 def test_fails_loudly_without_a_gpu(qps):
     from quadraticprogramsolver_amd import _lib
     if _lib.lib().qps_device_count() > 0:

@@ -210,6 +210,27 @@ def test_ldl_deep_elimination_tree(gpu, c_oracle, monkeypatch, n, bw, env):
     assert np.abs(x - xo).max() <= ABS_DEV_THR
 
 
+def test_ldl_chain_problem_beyond_the_dense_tail(gpu, c_oracle):
+    """n = 30 000 chain-structured problem (N = 59 999 KKT rows): the minimum-degree elimination tree is ~60 000 levels deep and no longer fits the
+    dense tail -- the plugin used to refuse it.  The analysis now dissects the breadth-first line order (ldl_symbolic.cpp: line_dissection_order),
+    a few hundred levels, and the iterates / the RunTests-style solve match the oracle's sparse L D L' (which orders with SuperLU's MMD)."""
+    n = 30000
+    P, q, A, l, u = _banded_problem(n, 2, make_rng(94, 0))
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="ldl") as prob:
+        x = np.zeros(n); info = {}
+        prob.solve(x, numIterations=30, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+        xo, io = c_oracle.solve(P, q, A, l, u, numIterations=30, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+        assert rel(x, xo) <= 1e-9
+        x = np.zeros(n); info = {}
+        t0 = time.perf_counter()
+        flag = prob.solve(x, numIterations=5000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True, info=info)
+        note(f"chain n={n}: flag {int(flag)} iterations {info['iterations']} refactor {info['numRefactor']} setup {info['tSetup']*1e3:.1f} ms loop {info['tLoop']*1e3:.1f} ms "
+             f"({info['tLoop']/max(info['iterations'],1)*1e6:.0f} us/iteration) call {(time.perf_counter()-t0)*1e3:.1f} ms")
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=5000, epsAbs=1e-6, epsRel=1e-6, rho=0.1, adptRho=True, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+    assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+    assert np.abs(x - xo).max() <= ABS_DEV_THR
+
+
 def test_ldl_refuses_a_tree_that_is_too_deep(gpu, monkeypatch):
     """More sparse levels than QPS_LDL_MAX_LEVELS: explicit QPS_ERR_UNSUPPORTED naming the CG plugin (no silent fallback)."""
     monkeypatch.setenv("QPS_LDL_MAX_TAIL", "64"); monkeypatch.setenv("QPS_LDL_MIN_LEVEL", "2"); monkeypatch.setenv("QPS_LDL_MAX_LEVELS", "16")
