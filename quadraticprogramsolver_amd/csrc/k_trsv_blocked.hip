@@ -147,26 +147,6 @@ __global__ __launch_bounds__(STREAM + 64) void k_trsv_blocked(const T* __restric
 
     // ---------------------------------------------------------------------------------------------------- streaming waves
     const int lane = tid & 63, wave = tid >> 6;
-    // right-hand side into this thread's own LDS slots (no other thread reads them before the courier has replaced the chunk)
-    for (int K0 = 0; K0 < nblk; K0 += 4) {
-        V tv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = min((K0 + k) * NB + tid * VN, NP - VN);               // unconditional (clamped) loads: exact load counting
-            tv[k] = *reinterpret_cast<const V*>(v + c);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = (K0 + k) * NB + tid * VN;
-            if (K0 + k < nblk) {
-                V x = tv[k];
-                if (c >= NP) { T* xp = reinterpret_cast<T*>(&x);
-#pragma unroll
-                    for (int e = 0; e < VN; ++e) xp[e] = T(0); }
-                *reinterpret_cast<V*>(vsh + c) = x;
-            }
-        }
-    }
     const int ttot = nblk * (nblk + 1) / 2;
     auto load = [&](V (&b)[RB], int p, int idx) {
         const int q = tile_phase(p, idx);
@@ -216,6 +196,27 @@ __global__ __launch_bounds__(STREAM + 64) void k_trsv_blocked(const T* __restric
     int lp = 0, lidx = 0, issued = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) { load(buf[w], lp, lidx); if (++issued < ttot) tile_next(lp, lidx); }
+    // right-hand side into this thread's own LDS slots (no other thread reads them before the courier has replaced the chunk); issued behind the
+    // first tiles so that both travel in the same memory round trip (the first tile needs t_0 anyway)
+    for (int K0 = 0; K0 < nblk; K0 += 4) {
+        V tv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = min((K0 + k) * NB + tid * VN, NP - VN);               // unconditional (clamped) loads: exact load counting
+            tv[k] = *reinterpret_cast<const V*>(v + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (K0 + k) * NB + tid * VN;
+            if (K0 + k < nblk) {
+                V x = tv[k];
+                if (c >= NP) { T* xp = reinterpret_cast<T*>(&x);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) xp[e] = T(0); }
+                *reinterpret_cast<V*>(vsh + c) = x;
+            }
+        }
+    }
     int cp = 0, cidx = 0;
     for (int s0 = 0; s0 < ttot; s0 += W) {
 #pragma unroll
