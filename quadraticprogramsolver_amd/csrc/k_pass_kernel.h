@@ -42,7 +42,10 @@ struct Pass {
                 if (c < NP) {
                     // A is streamed exactly once per iteration by exactly one CU: non-temporal, so that it does not evict the
                     // sweep triangle and the slabs from L2 / Infinity Cache (measured on C2: pass 49.9 -> 46.7 us, fused sweep
-                    // 23.5 -> 21.8 us; a run-time selectable hint was slower than either fixed choice, fp32 is insensitive)
+                    // 23.5 -> 21.8 us; a run-time selectable hint was slower than either fixed choice, fp32 is insensitive).
+                    // (Unconditional, clamped loads -- which let the compiler count the loads in flight instead of waiting for all of them in
+                    // front of every other tile, and do help the triangular sweeps -- make THIS kernel slower: C2 45.3 -> 58.4 us.  With both
+                    // tiles' requests counted the FMAs are woven between 32 single-register waits; the coarse wait keeps the tile whole.)
                     typedef T NV __attribute__((ext_vector_type(VN)));
                     const NV t = __builtin_nontemporal_load(reinterpret_cast<const NV*>(A + (int64_t)(row + i) * ld + c));
                     T* p = reinterpret_cast<T*>(&a[i][k]);
@@ -96,7 +99,9 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
         T* xp_ = reinterpret_cast<T*>(&xv[k]);
         if (c < NP) {
             xv[k] = *reinterpret_cast<const V*>(xx + c);
-            if (CHECK || (g == 0 && MODE != 2)) {
+            // (plain variant: workgroup 0 writes the relaxed x at the END of the kernel -- here its four load / wait / store round trips made it
+            // start streaming A ~3 us after the other 255 workgroups, and the launch lasts as long as its slowest workgroup)
+            if (CHECK) {
                 const V xo = *reinterpret_cast<const V*>(x_old + c);
                 const T* xop = reinterpret_cast<const T*>(&xo);
                 V xnv;
@@ -224,6 +229,25 @@ __global__ __launch_bounds__(THREADS) void k_apass(const T* __restrict__ A, int6
         if (haveB) {
             if (row + 2 * R < row1) { PS::load_tile(bufA, A, ld, row + 2 * R, NP, tid); prefetch_rows(row + 2 * R, zA, yA, lA, uA); }
             process(bufB, row + R, zB, yB, lB, uB);
+        }
+    }
+
+    if (!CHECK && MODE != 2 && g == 0) {
+        // x_new = alpha x~ + (1 - alpha) x_old (SolveQuadraticProgram.jl:57) by workgroup 0, all loads in flight together
+        V xo[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) xo[k] = *reinterpret_cast<const V*>(x_old + min(tid * VN + k * CHUNK, NP - VN));
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = tid * VN + k * CHUNK;
+            if (c < NP) {
+                const T* xp_ = reinterpret_cast<const T*>(&xv[k]);
+                const T* xop = reinterpret_cast<const T*>(&xo[k]);
+                V xnv; T* xnp = reinterpret_cast<T*>(&xnv);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) xnp[e] = alpha * xp_[e] + alpha1 * xop[e];
+                *reinterpret_cast<V*>(x_new + c) = xnv;
+            }
         }
     }
 

@@ -50,11 +50,12 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
         for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
+                // UNCONDITIONAL loads (threads right of the diagonal re-read the diagonal's own vector -- a line the row needs anyway; process() zeroes
+                // what lies above the diagonal): with a predicated load here the compiler could not count the loads in flight and waited for ALL of them
+                // (vmcnt(0)) before every tile -- the tile it had just requested included, so the double buffer never overlapped anything
                 const int c = tid * VN + k * CHUNK;
-                if (c < NP && c <= row + i) a[i][k] = *reinterpret_cast<const V*>(S + (int64_t)(row + i) * ld + c);
-                else { T* p = reinterpret_cast<T*>(&a[i][k]);
-#pragma unroll
-                    for (int e = 0; e < VN; ++e) p[e] = T(0); }
+                const int cc = min(min(c, (row + i) & ~(VN - 1)), NP - VN);
+                a[i][k] = *reinterpret_cast<const V*>(S + (int64_t)(row + i) * ld + cc);
             }
     };
     // A wave whose first column lies right of the diagonal holds only zeros of this row: it skips the dot, the reduction and the
@@ -103,12 +104,10 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
             load(bufA, tile_row(0));
             for (int it = 0; it < my_tiles; it += 2) {
                 const bool haveB = it + 1 < my_tiles;
-                if (haveB) load(bufB, tile_row(it + 1));
+                load(bufB, tile_row(min(it + 1, my_tiles - 1)));            // (past the end: the last tile again, never used -- no branch around a load)
                 process(bufA, tile_row(it), 0);
-                if (haveB) {
-                    if (it + 2 < my_tiles) load(bufA, tile_row(it + 2));
-                    process(bufB, tile_row(it + 1), 1);
-                }
+                load(bufA, tile_row(min(it + 2, my_tiles - 1)));
+                if (haveB) process(bufB, tile_row(it + 1), 1);
             }
         }
     } else {
