@@ -178,20 +178,25 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
     // software pipeline, two tasks deep: (col, val) slices and row pointers of the next two tasks are in flight while one is reduced
     struct Regs { int c[4]; T v[4]; int r[2]; int r0, r1, base, end; };
     Regs RA, RB;
+    // UNCONDITIONAL loads at clamped positions (an entry past the slice is read from the slice's last entry and marked c = -1 afterwards): a
+    // predicated load cannot be counted by the compiler, which then waits for every outstanding load (vmcnt(0)) before it touches ANY fetched
+    // register -- the two-tasks-deep pipeline below waited for the slices it had just requested before reducing the one it had
     auto fetch = [&](Regs& R, int i) {
         const int4 m = meta[i];
         R.r0 = m.x; R.r1 = m.y; R.base = m.z; R.end = m.w;
-        if (!(R.r1 - R.r0 == 1 && R.end - R.base > BCHUNK)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int k = R.base + tid + BTHREADS * j; R.c[j] = (k < R.end) ? (int)ci[k] : -1; R.v[j] = (k < R.end) ? va[k] : T(0); }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { const int r = R.r0 + tid + BTHREADS * j; R.r[j] = (r <= R.r1) ? rpb[r] : 0; }
+        for (int j = 0; j < 4; ++j) {
+            const int k = R.base + tid + BTHREADS * j, kk = max(min(k, R.end - 1), 0);
+            const int cj = (int)ci[kk]; R.v[j] = va[kk];
+            R.c[j] = (k < R.end) ? cj : -1;
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int r = R.r0 + tid + BTHREADS * j; R.r[j] = rpb[min(r, R.r1)]; }
     };
     auto process = [&](Regs& R, int inext) {
         const int r0 = R.r0, r1 = R.r1, base = R.base, end = R.end;
         if (r1 - r0 == 1 && end - base > BCHUNK) {              // one long row of this block: strided walk + block reduction
-            if (inext < nt) fetch(R, inext);
+            fetch(R, min(inext, nt - 1));                        // (past the end: the last task again, never used -- no branch around the loads)
             T s = T(0);
             for (int k = base + tid; k < end; k += BTHREADS) s += va[k] * xs[ci[k]];
             double d = (double)s;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
         for (int j = 0; j < 4; ++j) prod[tid + BTHREADS * j] = (R.c[j] >= 0) ? R.v[j] * xs[R.c[j]] : T(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) { const int i = tid + BTHREADS * j; if (i <= r1 - r0) rps[i] = R.r[j] - base; }
-        if (inext < nt) fetch(R, inext);                        // this register set is free again
+        fetch(R, min(inext, nt - 1));                           // this register set is free again
         __syncthreads();
         const int lane = tid & (LPR - 1);
         for (int i = tid / LPR; i < r1 - r0; i += BTHREADS / LPR) {
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
         __syncthreads();
     };
     fetch(RA, 0);
-    if (nt > 1) fetch(RB, 1);
+    fetch(RB, min(1, nt - 1));
 #pragma unroll
     for (int j = 0; j < XPT; ++j) xs[tid + BTHREADS * j] = xr[j];
     __syncthreads();                                            // xs complete
