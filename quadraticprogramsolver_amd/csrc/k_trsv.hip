@@ -229,14 +229,24 @@ template <typename T> static bool sweep_wave_covers(int NP) { return sweep_wave(
 
 template <typename T> bool sweep_fused_supported(int NP) { return NP <= 16 * 512 * VecOf<T>::N && NP >= 1024; }   // 16384 fp64 / 32768 fp32
 
-static int sweep_rb() { static int rb = [] { const char* e = getenv("QPS_SWEEP_RB"); return e ? atoi(e) : 2; }(); return rb; }   // fp64: 2-row tiles measured best
+// Rows per tile of the double-buffered variants: about 64 B per thread and tile (two tiles = 64 KB in flight per CU).  Measured with the exact-wait
+// loads (one MI355X, dispatch events): fp64 n = 4096 (KC 4) 18.0 / 16.0 / 15.6 us at 4 / 2 / 1 rows, fp32 n = 4096 (KC 2) 12.0 / 11.0 / 11.1 us --
+// more bytes in flight per CU make the sweep slower, not faster.  QPS_SWEEP_RB forces a value (1, 2, 4).
+static int sweep_rb_env() { static int rb = [] { const char* e = getenv("QPS_SWEEP_RB"); return e ? atoi(e) : 0; }(); return rb; }
+static int sweep_rb_for(int kc) {
+    int rb = sweep_rb_env() > 0 ? sweep_rb_env() : (kc >= 4 ? 1 : (kc == 2 ? 2 : 4));
+    if (rb != 1 && rb != 2 && rb != 4) rb = 2;
+    if (kc > 4 && rb == 4) rb = 2;        // (8 chunks x 4 rows x 2 tiles does not fit the register file)
+    return rb;
+}
 
 template <typename T> int sweep_fused_slabs(int NP, int count) {
     if (sweep_wave_covers<T>(NP)) {      // wave-per-row kernel: about one workgroup per CU over the whole launch, at least two rows per wave
         const int per = count >= 256 ? 1 : 256 / (count < 1 ? 1 : count);
         return std::max(1, std::min(per, NP / 16));
     }
-    int RB = (sweep_rb() == 2 && VecOf<T>::N == 2) ? 2 : 4;
+    const int kc0 = (NP + 512 * VecOf<T>::N - 1) / (512 * VecOf<T>::N);
+    int RB = sweep_rb_for(kc0);
     if (NP > 8 * 512 * VecOf<T>::N) RB = 1;   // wide single-buffered variants
     static const int total_env = [] { const char* e = getenv("QPS_SWEEP_WGS"); return e ? atoi(e) : 0; }();
     const int kc = (NP + 512 * VecOf<T>::N - 1) / (512 * VecOf<T>::N);
@@ -254,7 +264,7 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
     const int kc = (NP + chunk - 1) / chunk;
     const int G = sweep_fused_slabs<T>(NP, bs.count);
     dim3 grid(G, bs.count);
-    const bool rb2 = (sweep_rb() == 2 && VecOf<T>::N == 2);
+    const int rb = sweep_rb_for(kc);
     const LaunchTiming lt = g_launch_timing;   // profiled launch: the dispatch's own timestamps (qps_kernels.h)
     g_launch_timing = LaunchTiming();
     if (sweep_wave_covers<T>(NP)) {
@@ -277,9 +287,13 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
         if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused<T, TH, KC, 1, false>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \
         else hipLaunchKernelGGL((k_sweep_fused<T, TH, KC, 1, false>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs);      \
     } while (0)
+#define QPS_SR(KC) do { if (rb == 1) QPS_S(KC, 1); else if (rb == 2) QPS_S(KC, 2); else QPS_S(KC, 4); } while (0)
     if (kc > 8) { if (kc <= 12) QPS_SW(12); else QPS_SW(16); }
-    else if (rb2) { if (kc <= 1) QPS_S(1, 2); else if (kc <= 2) QPS_S(2, 2); else if (kc <= 4) QPS_S(4, 2); else QPS_S(8, 2); }
-    else     { if (kc <= 1) QPS_S(1, 4); else if (kc <= 2) QPS_S(2, 4); else if (kc <= 4) QPS_S(4, 4); else QPS_S(8, 2 * (VecOf<T>::N / 2)); }
+    else if (kc <= 1) QPS_SR(1);
+    else if (kc <= 2) QPS_SR(2);
+    else if (kc <= 4) QPS_SR(4);
+    else { if (rb == 1) QPS_S(8, 1); else QPS_S(8, 2); }
+#undef QPS_SR
 #undef QPS_SW
 #undef QPS_S
     return G;
