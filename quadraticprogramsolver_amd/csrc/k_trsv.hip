@@ -143,7 +143,7 @@ __global__ __launch_bounds__(THREADS) void k_sweep_fused(const T* __restrict__ S
 // and no barrier, the column accumulation stays in the wave's registers, and the eight waves of a workgroup add their column sums through LDS
 // once, at the end.  Rows are dealt cyclically over all waves of a QP, longest first.  Same slab interface as k_sweep_fused.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int KCW>
+template <typename T, int KCW, bool DB = true>
 __global__ __launch_bounds__(512) void k_sweep_fused_wave(const T* __restrict__ S, int64_t ld, int NP, const T* __restrict__ v,
                                                           T* __restrict__ part, int64_t part_ld, BatchStride bs) {
     using V = typename VecOf<T>::type;
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(512) void k_sweep_fused_wave(const T* __restrict__ 
         }
     };
     const int mine = w < NP ? (NP - w + W - 1) / W : 0;
-    if (mine > 0) {
+    if constexpr (!DB) {
+        V buf[KCW];
+        for (int it = 0; it < mine; ++it) { load(buf, row_of(it)); process(buf, row_of(it)); }
+    } else if (mine > 0) {
         V bufA[KCW], bufB[KCW];
         load(bufA, row_of(0));
         for (int it = 0; it < mine; it += 2) {
@@ -273,7 +276,12 @@ int sweep_fused(hipStream_t st, const T* S, int64_t ld, int NP, const T* v, T* p
         if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused_wave<T, KCW>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); \
         else hipLaunchKernelGGL((k_sweep_fused_wave<T, KCW>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs);              \
     } while (0)
-        if (NP <= 64 * VecOf<T>::N * 4) QPS_WV(4); else QPS_WV(8);
+        // one row per wave in flight (no second row prefetched): 250-252 k -> 254.3 k QP-it/s on the 32-QP slab of C4 -- the eight independent waves of a
+        // workgroup already overlap each other, a second row per wave only adds requests in flight (QPS_SWEEP_WAVE_DB=1 prefetches it)
+        static const int wave_db = [] { const char* e = getenv("QPS_SWEEP_WAVE_DB"); return e ? atoi(e) : 0; }();
+        if (NP <= 64 * VecOf<T>::N * 4) QPS_WV(4);
+        else if (wave_db == 0) { if (lt.start) hipExtLaunchKernelGGL((k_sweep_fused_wave<T, 8, false>), grid, dim3(TH), 0, st, lt.start, lt.stop, 0, S, ld, NP, v, part, part_ld, bs); else hipLaunchKernelGGL((k_sweep_fused_wave<T, 8, false>), grid, dim3(TH), 0, st, S, ld, NP, v, part, part_ld, bs); }
+        else QPS_WV(8);
 #undef QPS_WV
         return G;
     }
