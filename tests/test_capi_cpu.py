@@ -205,6 +205,38 @@ def test_ldl_analysis_of_chain_like_problems_falls_back_to_line_dissection(qps, 
     assert rep["numRows"] == 199999 and rep["numSparseLevels"] <= 600 and rep["nnzL"] <= 12 * rep["nnzK"]
 
 
+def test_ldl_analysis_randomised_patterns_with_forced_line_dissection(qps, monkeypatch):
+    """Random band / sparse / block-diagonal / path patterns (disconnected graphs and m = 0 included) with limits that push the analysis through its
+    line-dissection fallback: always a permutation, and nnz(L) equals an independent boolean elimination under that ordering."""
+    import scipy.sparse as sp
+    for k, v in {"QPS_LDL_MAX_TAIL": "32", "QPS_LDL_MIN_LEVEL": "4", "QPS_LDL_DISSECT_LEVELS": "8", "QPS_LDL_MAX_LEVELS": "100000"}.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(3)
+    for c in range(32):
+        n = int(rng.integers(20, 200)); m = int(rng.integers(0, 2 * n))
+        kind = ["band", "rand", "blocks", "path2"][c % 4]
+        if kind == "band":
+            bw = int(rng.integers(1, 5)); m = min(m, n - 1)
+            P = sp.diags([np.ones(n - k) for k in range(bw + 1)] + [np.ones(n - k) for k in range(1, bw + 1)],
+                         list(range(bw + 1)) + [-k for k in range(1, bw + 1)], format="csc")
+            A = sp.diags([np.ones(m), np.ones(m)], [0, 1], shape=(m, n), format="csc") if m > 0 else sp.csc_matrix((0, n))
+        elif kind == "rand":
+            M = sp.random(n, n, density=2.0 / n, random_state=rng, format="csc"); P = (M + M.T + sp.identity(n)).tocsc()
+            A = sp.random(m, n, density=1.5 / n, random_state=rng, format="csc")
+        elif kind == "blocks":
+            b = max(2, n // int(rng.integers(2, 9)))
+            P = sp.block_diag([np.ones((min(b, n - i), min(b, n - i))) for i in range(0, n, b)], format="csc")
+            A = sp.random(m, n, density=0.5 / n, random_state=rng, format="csc")
+        else:
+            P = sp.identity(n, format="csc"); rows = np.arange(m) % max(n - 2, 1)
+            A = sp.csc_matrix((np.ones(2 * m), (np.r_[np.arange(m), np.arange(m)], np.r_[rows, rows + 2])), shape=(m, n)) if m > 0 else sp.csc_matrix((0, n))
+        perm, rep = _analyze(P, A)
+        N = n + m
+        assert sorted(perm.tolist()) == list(range(N)), (c, kind)
+        K = sp.bmat([[sp.csc_matrix(P) + sp.eye(n), sp.csc_matrix(A).T], [sp.csc_matrix(A), -sp.eye(m)]], format="csr") if m > 0 else (sp.csc_matrix(P) + sp.eye(n)).tocsr()
+        assert rep["nnzL"] == _symbolic_nnz(K, perm) and rep["numRows"] == N == rep["numSparseColumns"] + rep["tailSize"], (c, kind, rep)
+
+
 def test_fails_loudly_without_a_gpu(qps):
     from quadraticprogramsolver_amd import _lib
     if _lib.lib().qps_device_count() > 0:
