@@ -10,7 +10,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
 t0 = time.time()
 for c in range(cases):
-    kind = rng.choice(["dense", "dense", "dense", "cg", "ldl", "batch"])
+    kind = rng.choice(os.environ.get("FUZZ_KINDS", "dense,dense,dense,cg,ldl,batch").split(","))
     dtype = "f64" if rng.random() < 0.75 else "f32"
     if kind == "dense":
         n = int(rng.choice([3, 17, 64, 65, 100, 129, 300, 511, 513, 1000, 1024, 1025, 1500, 2049, 2300]))
