@@ -11,7 +11,9 @@ resident in HBM with its factorisation cached (setup is reported separately, BAS
 `cpu_baseline` (the oracle's C restatement on this box's host cores, bounded sample; rank 0 at N = 1 only).
 """
 import argparse
+import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -21,6 +23,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+KEEP = {}                  # the headline problem, kept for the fp32 leg of `side_configs`
+LAST_TRAFFIC_META = {}     # filled by pmc_traffic(): build identity of the PMC summary the last traffic figure came from
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
 HBM_ACHIEVABLE_GBS = 6290.0
 
@@ -71,6 +75,8 @@ def main():
     ap.add_argument("--trsv-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-eps", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="default command only (config c2, one GPU): skip the GPU legs of c5 / c4 / c3 that are appended as `side_configs`")
     ap.add_argument("--profile-level", type=int, default=1,
                     help="1: HIP events on sampled dispatches of the loop kernels (well under 1 %% overhead); 2: every launch of every kernel")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -101,6 +107,10 @@ def main():
     sync = (lambda: torch.cuda.synchronize()) if torch.cuda.is_available() else (lambda: None)
     run = {"c2": run_dense, "c5": run_dense, "c1": run_dense, "c3": run_sparse, "c4": run_batch}[args.config]
     out = run(args, cfg, info, device, qps, qd, np, sync)
+    if args.config == "c2" and info.world_size == 1 and not args.no_side_configs and args.trsv_block == 0:
+        # every BASELINE config in the one driver-run line (RunBenchmarks.jl:88-104: one run covers every test): GPU legs only, after the
+        # headline's timed region, each a shortened run of exactly what `bench.py --config cX` measures
+        out["side_configs"] = side_configs(args, info, device, qps, qd, np, sync)
     if info.rank == 0:
         out["config"]["dist_backend"] = backend
         out["config"]["ranks"] = info.world_size
@@ -115,6 +125,33 @@ def base_line(args, cfg, info, value, tmax, scaling, metric="ADMM iterations/sec
             "dtype": cfg["dtype"], "data": "synthetic", "config": {"workload": cfg["label"], "n": cfg["n"], "m": cfg["m"], "admm_iterations_per_step": args.iters}}
 
 
+def csrc_digest():
+    """Identity of the kernel sources the running library was built from: sha256 over the sorted files of csrc/ and include/qps.h.  The PMC
+    summaries under profiles/ carry the digest of the tree they were measured on; a figure measured on other sources is not reported."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "quadraticprogramsolver_amd", "csrc")
+    files = sorted(f for f in os.listdir(base) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    for f in files + [os.path.join("..", "..", "include", "qps.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(os.path.join(base, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_head():
+    """git HEAD of the tree (the GPU box has no .git: tests/tools/gpu.sh stamps .build_head before shipping the snapshot)."""
+    try:
+        import subprocess
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()[:12]
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".build_head")).read().strip()[:12] or None
+    except Exception:
+        return None
+
+
 def roofline_of(kernel_label, seconds, launches, algo_bytes_per_launch, traffic, traffic_src, extra=None):
     dur = seconds / launches
     ach = algo_bytes_per_launch / dur / 1e9
@@ -124,24 +161,71 @@ def roofline_of(kernel_label, seconds, launches, algo_bytes_per_launch, traffic,
     if traffic:
         r["traffic_over_algorithmic"] = round(traffic / algo_bytes_per_launch, 3)
         r["traffic_GBs"] = round(traffic / dur / 1e9, 1)
+    r["traffic_head"] = LAST_TRAFFIC_META.get("head")            # build the PMC passes ran on (null: no matching summary)
+    r["traffic_csrc_sha16"] = LAST_TRAFFIC_META.get("csrc_sha16")
+    r["running_csrc_sha16"] = csrc_digest()
+    if LAST_TRAFFIC_META.get("stale"):
+        r["traffic_note"] = LAST_TRAFFIC_META["stale"]
     if extra:
         r.update(extra)
     return r
 
 
-def kernel_list(ktimes):
-    return [{"name": k["name"], "avg_us": round(k["seconds"] / k["launches"] * 1e6, 2), "launches": k["launches"],
-             "GBs": round(k["algo_bytes"] / (k["seconds"] / k["launches"]) / 1e9, 1) if k["algo_bytes"] > 0 else None} for k in ktimes]
+# rocprofv3 kernel names of the profiler categories (for the side-by-side averages in `kernels[]`)
+ROCPROF_NAME = [(r"^apass\(fused A-pass", r"k_apass<.*false, 0>"), (r"^apass\(check variant", r"k_apass<.*true, 0>"),
+                (r"^sweeps\(fused", r"k_sweep_fused(_wave)?<"), (r"^colsum\(", r"k_colsum<"), (r"^trsv_forward", r"k_trsv_blocked<.*false, \d+>"),
+                (r"^trsv_backward", r"k_trsv_blocked<.*true, \d+>"), (r"^spmv_blk\(", r"k_spmv_blk<"), (r"^admm_small", r"k_admm_small")]
+
+
+def rocprof_stats(config):
+    """Average kernel durations from the committed `rocprofv3 --kernel-trace --stats` summary of this config's command
+    (profiles/rNN_*bench_<config>_kernel_stats.csv, newest), only when it was taken on the sources now running (side-car .meta.json)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*bench_{config}_kernel_stats.csv")))
+    for f in reversed(files):
+        try:
+            meta = json.load(open(f[:-4] + ".meta.json"))
+        except Exception:
+            continue
+        if meta.get("csrc_sha16") != csrc_digest():
+            continue
+        rows = {}
+        for r in csv.DictReader(open(f)):
+            rows[r["Name"]] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
+        return rows, os.path.basename(f)
+    return {}, None
+
+
+def kernel_list(ktimes, config=None, iters_per_s=None):
+    """Per-kernel averages.  `avg_us` = HIP events attached to the sampled dispatches (they read ~1-2 us longer per launch than the kernel's own
+    duration: the sum over an iteration's launches can exceed the wall time per iteration); `rocprof_avg_us` = the same kernel in the committed
+    rocprofv3 --kernel-trace --stats summary of this command, when one exists for the running sources."""
+    rows, src = rocprof_stats(config) if config else ({}, None)
+    out = []
+    for k in ktimes:
+        e = {"name": k["name"], "avg_us": round(k["seconds"] / k["launches"] * 1e6, 2), "launches": k["launches"],
+             "GBs": round(k["algo_bytes"] / (k["seconds"] / k["launches"]) / 1e9, 1) if k["algo_bytes"] > 0 else None, "rocprof_avg_us": None}
+        pat = next((rp for cp, rp in ROCPROF_NAME if re.search(cp, k["name"])), None)
+        if pat and rows:
+            hit = [(n, v) for n, v in rows.items() if re.search(pat, n)]
+            if hit:
+                name, (avg, calls) = max(hit, key=lambda t: t[1][1])
+                e["rocprof_avg_us"] = round(avg, 2)
+        out.append(e)
+    if src:
+        out.append({"name": "_rocprof_source", "file": f"profiles/{src}"})
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
 # dense single-QP configs: c2 (headline), c5 (fp32 + refactor per check), c1 (plumbing shape, single-launch loop)
 # ----------------------------------------------------------------------------------------------------------------------------------
-def run_dense(args, cfg, info, device, qps, qd, np, sync):
+def run_dense(args, cfg, info, device, qps, qd, np, sync, problem=None):
     n, m = cfg["n"], cfg["m"]
     s = 8 if cfg["dtype"] == "f64" else 4
     # synthetic input: randomQp at density 1.0, seed 1234, one independent stream per rank (weak scaling: replicas)
-    P, q, A, l, u = qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank)
+    P, q, A, l, u = problem if problem is not None else qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=info.rank)
+    if args.config == "c2":
+        KEEP["c2_problem"] = (P, q, A, l, u)       # c5 of `side_configs` is the same problem in fp32
     prob = qps.QuadraticProgram(P, q, A, l, u, dtype=cfg["dtype"], device=device)
     solve_kw = dict(numIterations=args.iters, ϵAbs=0.0, ϵRel=0.0, trsvBlock=args.trsv_block, reuseFactor=True)
     if args.config == "c5":
@@ -189,7 +273,7 @@ def run_dense(args, cfg, info, device, qps, qd, np, sync):
         out["setup_ms"] = round(setup_info.get("tSetup", 0.0) * 1e3, 2)
         if refactors:
             out["refactor"] = {"count": refactors, "ms_each": round(t_refactor / refactors * 1e3, 3), "share_of_loop_time": round(t_refactor / elapsed, 3)}
-        out["kernels"] = kernel_list(ktimes)
+        out["kernels"] = kernel_list(ktimes, args.config)
         sw = next((k for k in ktimes if k["name"].startswith("sweeps(fused")), None)
         if sw:   # the fused kernel reads the triangle once; SURVEY §8d's figure for the two sweeps it replaces is s*(n(n+1) + 4n)
             dur = sw["seconds"] / sw["launches"]
@@ -224,9 +308,69 @@ def run_dense(args, cfg, info, device, qps, qd, np, sync):
                                       "ms_setup": round(ti["tSetup"] * 1e3, 2), "ms_loop": round(ti["tLoop"] * 1e3, 2),
                                       "problem": "randomQp density 1.0, bounds centred on A*x0 (feasible variant)"}
             del Pf, Af
-        out["cpu_baseline"] = cpu_baseline_dense(P, q, A, l, u, args.config) if (not args.no_cpu_baseline and info.world_size == 1) else None
+        out["cpu_baseline"], out["parity"] = None, None
+        if not args.no_cpu_baseline and info.world_size == 1:
+            # the oracle solved this very problem for a fixed K (the cpu_baseline sample): run the HIP path for the same K once, outside the
+            # timed region, and put the two side by side (SolveQuadraticProgram.jl:45-71; iterate-level tolerance of SURVEY §8c, fp32: 1e-3)
+            out["cpu_baseline"], ref = cpu_baseline_dense(P, q, A, l, u, args.config)
+            xg = np.zeros(n); gi = {}
+            prob.solve(xg, **dict(solve_kw, numIterations=ref["K"]), info=gi)
+            zg, yg = prob.dual()
+            tol = 1e-9 if cfg["dtype"] == "f64" else 1e-3
+            out["parity"] = parity_block(np, ref, xg, zg, yg, gi, tol, "oracle/qps_oracle.c (fp64 C restatement of the reference loop), same problem, same parameters"
+                                         + (", same refactor-per-check schedule; HIP path in fp32" if args.config == "c5" else ""))
     prob.close()
     return out
+
+
+def side_configs(args, info, device, qps, qd, np, sync):
+    """GPU legs of BASELINE configs[4] (c5), configs[3] (c4, all 256 QPs on this GPU) and configs[2] (c3), run after the headline's timed
+    region with the very functions `bench.py --config cX` runs (shorter: fewer steps, no CPU baseline, no time-to-eps)."""
+    res = {"note": "GPU legs only, measured after the headline timed region by the code path of `bench.py --config cX` (fewer steps); the full lines "
+                   "with cpu_baseline / parity / time_to_eps are profiles/rNN_*_bench_cX.json"}
+    t_all = time.perf_counter()
+    for name, steps in (("c5", 6), ("c4", 3), ("c3", 5)):
+        t0 = time.perf_counter()
+        try:
+            sa = argparse.Namespace(**vars(args))
+            sa.config, sa.steps, sa.warmup, sa.iters = name, steps, 1, {"c3": 100, "c4": 100}.get(name, 500)
+            sa.no_cpu_baseline = sa.no_time_to_eps = True
+            cfg = CONFIGS[name]
+            if name == "c5":
+                o = run_dense(sa, cfg, info, device, qps, qd, np, sync, problem=KEEP.pop("c2_problem", None))
+            elif name == "c4":
+                o = run_batch(sa, cfg, info, device, qps, qd, np, sync)
+            else:
+                o = run_sparse(sa, cfg, info, device, qps, qd, np, sync)
+            rf, lr = o.get("roofline") or {}, o.get("loop_roofline") or {}
+            e = {"workload": cfg["label"], "value": o["value"], "unit": o["unit"], "metric": o["metric"], "dtype": o["dtype"], "steps": steps, "warmup": 1,
+                 "admm_iterations_per_step": sa.iters, "ms_per_step": o["ms_per_step"],
+                 "roofline": {k: rf.get(k) for k in ("kernel", "frac", "achieved", "avg_launch_us", "algo_bytes_per_launch", "traffic", "traffic_head")},
+                 "loop_roofline_frac_of_8TBs": lr.get("frac_of_8TBs"), "refactor": o.get("refactor"), "sweep_variant": o["config"].get("sweep_variant"),
+                 "params": o["config"].get("params")}
+            if name == "c3":
+                e["cg_iterations_per_s"] = o.get("cg_iterations_per_s")
+            if name == "c4":
+                e["qps_on_this_gpu"] = o["config"].get("qps_on_rank0")
+            e["wall_s"] = round(time.perf_counter() - t0, 1)
+            res[name] = e
+        except Exception as ex:          # a side config must never take the headline line down with it
+            res[name] = {"error": f"{type(ex).__name__}: {ex}"[:300], "wall_s": round(time.perf_counter() - t0, 1)}
+    KEEP.clear()
+    res["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return res
+
+
+def parity_block(np, ref, x, z, y, gi, tol, against, extra=None):
+    """max relative deviation (max|a - b| / max(1, max|b|)) of the HIP path's x / z / y after K iterations from the oracle's."""
+    rel = lambda a, b: float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) if b.size else 0.0
+    dx, dz, dy = rel(x, ref["x"]), rel(z, ref["z"]), rel(y, ref["y"])
+    same = (gi.get("iterations") == ref["iterations"]) and (gi.get("numRefactor", 0) == ref["numRefactor"])
+    blk = {"K": ref["K"], "max_rel_dev_x": dx, "z": dz, "y": dy, "tolerance": tol, "ok": bool(max(dx, dz, dy) <= tol and same),
+           "iterations": [gi.get("iterations"), ref["iterations"]], "refactorisations": [gi.get("numRefactor", 0), ref["numRefactor"]], "against": against}
+    if extra:
+        blk.update(extra)
+    return blk
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
@@ -278,8 +422,16 @@ def run_sparse(args, cfg, info, device, qps, qd, np, sync):
         out["cg_iterations_per_admm_iteration"] = round(cg_per_admm, 2)
         out["loop_roofline"] = {"algo_bytes_per_cg_iteration": cg_bytes, "achieved_GBs": round(cg_bytes * cg["n"] / elapsed / 1e9, 1),
                                 "frac_of_8TBs": round(cg_bytes * cg["n"] / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
-        out["kernels"] = kernel_list(ktimes)
-        out["cpu_baseline"] = cpu_baseline_sparse(P, q, A, l, u) if (not args.no_cpu_baseline and info.world_size == 1) else None
+        out["kernels"] = kernel_list(ktimes, "c3")
+        out["cpu_baseline"], out["parity"] = None, None
+        if not args.no_cpu_baseline and info.world_size == 1:
+            out["cpu_baseline"], ref = cpu_baseline_sparse(P, q, A, l, u)
+            xg = np.zeros(n); gi = {}
+            solver.solve(xg, numIterations=ref["K"], ϵAbs=0.0, ϵRel=0.0, ϵPcg=1e-12, numItrPcg=5000, info=gi)
+            zg, yg = solver.dual()
+            out["parity"] = parity_block(np, ref, xg, zg, yg, gi, 1e-7, "oracle/qps_oracle.c, matrix-free CG plugin (LinearSystemSolvers.jl:145-186), same problem; inner CG "
+                                         "driven to epsPcg = 1e-12 on both sides so that the inexact solve does not separate them",
+                                         {"cg_iterations": [gi.get("cgIterations"), ref["cgIterations"]]})
     solver.close()
     return out
 
@@ -290,7 +442,7 @@ def run_sparse(args, cfg, info, device, qps, qd, np, sync):
 def run_batch(args, cfg, info, device, qps, qd, np, sync):
     n, m = cfg["n"], cfg["m"]
     begin, end = qd.shard_range(cfg["batch"], info.rank, info.world_size)      # QP b -> rank b // ceil(256 / world)
-    probs = [qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b) for b in range(begin, end)]
+    probs = generate_batch(qps, n, m, range(begin, end))
     solver = qps.QuadraticProgramBatch(probs, dtype=cfg["dtype"], device=device)
     first = probs[0]
     del probs
@@ -326,12 +478,18 @@ def run_batch(args, cfg, info, device, qps, qd, np, sync):
             out["roofline"] = None
         out["loop_roofline"] = {"algo_bytes_per_qp_iteration": b_iter, "achieved_GBs": round(b_iter * per_gpu / 1e9, 1),
                                 "frac_of_8TBs": round(b_iter * per_gpu / 1e9 / HBM_PEAK_GBS, 4), "frac_of_6.29TBs": round(b_iter * per_gpu / 1e9 / HBM_ACHIEVABLE_GBS, 4)}
-        out["kernels"] = kernel_list(ktimes)
-        out["cpu_baseline"] = cpu_baseline_batch(first, cfg["batch"]) if (not args.no_cpu_baseline and info.world_size == 1) else None
+        out["kernels"] = kernel_list(ktimes, "c4")
+        out["cpu_baseline"], out["parity"] = None, None
+        if not args.no_cpu_baseline and info.world_size == 1:
+            out["cpu_baseline"], ref = cpu_baseline_batch(first, cfg["batch"])
+            Xg, _, gis = solver.solve(numIterations=ref["K"], ϵAbs=0.0, ϵRel=0.0, reuseFactor=True)
+            Zg, Yg = solver.dual()
+            out["parity"] = parity_block(np, ref, Xg[0], Zg[0], Yg[0], gis[0], 1e-9, "oracle/qps_oracle.c on QP 0 of the batch (the batched launches carried all "
+                                         f"{end - begin} QPs of the rank), same parameters")
     solver.close()
     if info.rank == 0 and not args.no_time_to_eps:
         # time-to-eps of this rank's slab on the feasible variant (every QP runs to its own stopping iteration, per-QP rho switches)
-        probs = [qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b, feasible=True) for b in range(begin, min(end, begin + 32))]
+        probs = generate_batch(qps, n, m, range(begin, min(end, begin + 32)), feasible=True)
         with qps.QuadraticProgramBatch(probs, dtype=cfg["dtype"], device=device) as sb:
             t1 = time.perf_counter()
             _, flags, infos2 = sb.solve(numIterations=50000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
@@ -341,6 +499,28 @@ def run_batch(args, cfg, info, device, qps, qd, np, sync):
                                   "flags": sorted(set(int(f) for f in flags)), "refactorisations_max": max(i["numRefactor"] for i in infos2),
                                   "problem": "randomQp density 1.0, bounds centred on A*x0 (feasible variant), first 32 QPs of rank 0's slab"}
     return out
+
+
+def usable_cores():
+    """min(affinity mask, cgroup CPU quota): a GPU box shows every host core in the mask while the job's share is 16."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except Exception:
+        c = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            c = min(c, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, c)
+
+
+def generate_batch(qps, n, m, streams, feasible=False):
+    """The QPs of a slab, generated on a few host threads (one counter-based stream per QP: the order of generation does not matter)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(8, usable_cores()))) as ex:
+        return list(ex.map(lambda b: qps.GenerateDenseBenchmarkQP(n, m, seed=1234, stream=b, feasible=feasible), streams))
 
 
 def set_batch_profiling(solver, level):
@@ -379,16 +559,22 @@ def pmc_traffic(config, kernel_regex):
     """HBM bytes per launch of a kernel from the committed PMC passes of this config (rocprofv3 --pmc FETCH_SIZE and, in a separate
     pass, --pmc WRITE_SIZE on this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; tests/tools/pmc_summary.py).  PMC
     counters cannot be read from inside the timed process, so the figure comes from the newest profiles/rNN_*pmc_traffic_<config>.json."""
+    LAST_TRAFFIC_META.clear()
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*pmc_traffic_{config}.json")))
-    if not files and config == "c2":
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
     if not files:
         return None, None
     try:
         d = json.load(open(files[-1]))
+        meta = d.get("_meta") or {}
+        if meta.get("csrc_sha16") != csrc_digest():
+            # measured on other kernel sources (or before summaries carried their build): not this build's traffic
+            LAST_TRAFFIC_META.update(stale=f"profiles/{os.path.basename(files[-1])} was measured on csrc {meta.get('csrc_sha16')} (HEAD {meta.get('head')}), "
+                                           f"the running build is csrc {csrc_digest()}: traffic not reported")
+            return None, None
+        LAST_TRAFFIC_META.update(head=meta.get("head"), csrc_sha16=meta.get("csrc_sha16"))
         best = None
         for name, v in d.items():
-            if re.search(kernel_regex, name) and (best is None or v.get("launches", v.get("launches_sampled", 0)) > best[1].get("launches", best[1].get("launches_sampled", 0))):
+            if name != "_meta" and re.search(kernel_regex, name) and (best is None or v.get("launches", v.get("launches_sampled", 0)) > best[1].get("launches", best[1].get("launches_sampled", 0))):
                 best = (name, v)
         if best:
             return best[1]["hbm_bytes_per_launch"], f"profiles/{os.path.basename(files[-1])}: {best[0]} (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
@@ -411,13 +597,14 @@ def cpu_baseline_dense(P, q, A, l, u, config):
         kw.update(adptRho=True, fctrRho=1.0, numItrConv=50, rho=0.1)
     its = 100 if config != "c1" else 20000
     x, i_all = co.solve(P, q, A, l, u, numIterations=its, numThreads=cores, **kw)
-    x, i_one = co.solve(P, q, A, l, u, numIterations=max(its // 5, 10), numThreads=cores, loopThreads=1, **kw)
+    ref = {"K": its, "x": x, "z": i_all["z"], "y": i_all["y"], "iterations": i_all["iterations"], "numRefactor": i_all["numRefactor"]}
+    _, i_one = co.solve(P, q, A, l, u, numIterations=max(its // 5, 10), numThreads=cores, loopThreads=1, **kw)
     sample = (f"same problem as the GPU run: full setup + {its} ADMM iterations on all cores (OpenMP; blocked triangular solves); single-thread loop rate from "
               f"{max(its // 5, 10)} more iterations" + ("; refactor at every check (fp64 oracle: no fp32 CPU path)" if config == "c5" else ""))
     return {"value": round(its / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample,
             "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(max(its // 5, 10) / i_one["tLoop"], 3),
             "refactorisations_in_sample": i_all["numRefactor"],
-            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
+            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}, ref
 
 
 def cpu_baseline_sparse(P, q, A, l, u):
@@ -426,10 +613,13 @@ def cpu_baseline_sparse(P, q, A, l, u):
     cores = co.available_cores()
     x, i_all = co.solve(P, q, A, l, u, numIterations=10, epsAbs=0.0, epsRel=0.0, numThreads=cores, linsys=co.KIND_CG_MATFREE)
     x, i_one = co.solve(P, q, A, l, u, numIterations=4, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1, linsys=co.KIND_CG_MATFREE)
+    # the parity reference: K = 5 with the inner CG driven to 1e-12 (at the benchmark's epsPcg = 1e-6 two correct CG codes differ by ~1e-6)
+    xr, ir = co.solve(P, q, A, l, u, numIterations=5, epsAbs=0.0, epsRel=0.0, numThreads=cores, linsys=co.KIND_CG_MATFREE, epsPcg=1e-12, numItrPcg=5000)
+    ref = {"K": 5, "x": xr, "z": ir["z"], "y": ir["y"], "iterations": ir["iterations"], "numRefactor": ir["numRefactor"], "cgIterations": ir["cgIterations"]}
     return {"value": round(10 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": "same problem as the GPU run: 10 ADMM iterations (matrix-free CG, epsPcg 1e-6) on all cores (OpenMP over the CSC columns); single-thread rate from 4 more",
             "cg_iterations_per_s": round(i_all["cgIterations"] / i_all["tLoop"], 1), "single_thread_iterations_per_s": round(4 / i_one["tLoop"], 3),
-            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
+            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}, ref
 
 
 def cpu_baseline_batch(first, batch):
@@ -438,11 +628,12 @@ def cpu_baseline_batch(first, batch):
     cores = co.available_cores()
     P, q, A, l, u = first
     x, i_all = co.solve(P, q, A, l, u, numIterations=200, epsAbs=0.0, epsRel=0.0, numThreads=cores)
-    x, i_one = co.solve(P, q, A, l, u, numIterations=200, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1)
+    ref = {"K": 200, "x": x, "z": i_all["z"], "y": i_all["y"], "iterations": i_all["iterations"], "numRefactor": i_all["numRefactor"]}
+    _, i_one = co.solve(P, q, A, l, u, numIterations=200, epsAbs=0.0, epsRel=0.0, numThreads=cores, loopThreads=1)
     return {"value": round(200 / i_all["tLoop"], 3), "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": f"QP 0 of the batch: full setup + 200 ADMM iterations on all cores; the {batch} QPs would run back to back at this QP-iteration rate",
             "setup_s": round(i_all["tSetup"], 3), "single_thread_iterations_per_s": round(200 / i_one["tLoop"], 3),
-            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}
+            "note": "CPU restatement of the reference algorithm (oracle/qps_oracle.c); Julia is absent on this box"}, ref
 
 
 if __name__ == "__main__":

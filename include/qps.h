@@ -16,7 +16,8 @@
  *
  * Everything crossing this boundary is a plain pointer, size or scalar.  Host arrays stay owned by the caller and may
  * be freed as soon as the call that received them returns (qps_create_* copies the problem into HBM).
- * A handle is bound to one device and one HIP stream; distinct handles may be driven from distinct host threads, a
+ * A handle is bound to one device and one HIP stream; distinct handles -- on one device or on several devices of the process --
+ * may be driven from distinct host threads (per-device state of the library is keyed by device ordinal), a
  * single handle is not thread-safe.  All functions return a qps_status (0 = ok).
  */
 #ifndef QPS_H
@@ -121,6 +122,9 @@ typedef struct {
                                 3 = explicit inverse, two triangular GEMVs, 4 = single-launch small-problem loop,
                                 5 = blocked substitution, ONE launch per sweep (n / trsvBlock dependent phases handed from workgroup to
                                     workgroup inside the launch; trsvBlock = 1024 or 512 fp64, 2048 or 1024 fp32); 0 otherwise */
+    int32_t sweepGaveUp;     /* times a variant-5 launch of this solve gave up waiting for its workgroups (only another PROCESS running the
+                                same kernel on the card can cause that) and the solve was repeated on variant 1; its time is in tLoop */
+    int32_t reserved1;
 } qps_info;
 
 /* Fill *p with the reference defaults (SolveQuadraticProgram.jl:15-17). */
@@ -164,7 +168,8 @@ typedef struct {
 } qps_polish_report;
 int32_t qps_polish(qps_handle h, double *x_inout, const double *y, const qps_params *params, qps_polish_report *report);
 
-/* Final z and y of the last qps_solve (length m each; either pointer may be NULL). Additive. */
+/* Final z and y of the last qps_solve (length m each; batch handles: [count][m] each, of the last qps_solve_batch; either pointer
+ * may be NULL). Additive. */
 int32_t qps_get_dual(qps_handle h, double *z_out, double *y_out);
 
 /* The reference plugin pair, literally (host vectors in, device solve, host vectors out):

@@ -59,7 +59,7 @@ class QpsInfo(C.Structure):
                 ("cgIterations", C.c_int32), ("rhoFinal", C.c_double), ("rhoProposed", C.c_double),
                 ("resPrim", C.c_double), ("resDual", C.c_double), ("tSetup", C.c_double), ("tLoop", C.c_double),
                 ("tRefactor", C.c_double), ("polishFlag", C.c_int32), ("polishIterations", C.c_int32), ("tPolish", C.c_double),
-                ("trsvBlock", C.c_int32), ("sweepVariant", C.c_int32)]
+                ("trsvBlock", C.c_int32), ("sweepVariant", C.c_int32), ("sweepGaveUp", C.c_int32), ("reserved1", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -505,11 +505,11 @@ void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int 
     static const int th_env = [] { const char* e = getenv("QPS_SMALL_THREADS"); return e ? atoi(e) : 0; }();
     // few waves for tiny problems (a workgroup barrier costs with the number of waves), 1024 threads once there is work for them
     const int th = th_env > 0 ? th_env : ((int64_t)MP * NP <= 65536 ? 512 : 1024);   // measured at n = 10 / 64 / 100: 512 beats 256 and 1024
-    static bool attr_set[2][3][2] = {};
-    const int ti = sizeof(T) == 8 ? 0 : 1;
+    static PerDeviceOnce attr_set[2][3][2];   // the LDS attribute is a setting of the DEVICE's code object: once per device ordinal
+    const int ti = sizeof(T) == 8 ? 0 : 1, dev_ = current_device();
 #define QPS_SMALL(THN, IDX, LMV)                                                                                                             \
     do {                                                                                                                                     \
-        if (!attr_set[ti][IDX][LMV]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN, (LMV) != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[ti][IDX][LMV] = true; } \
+        if (attr_set[ti][IDX][LMV].first(dev_)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN, (LMV) != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((k_admm_small<T, THN, (LMV) != 0>), dim3(1), dim3(THN), lds, st, a, A, At, P, S, q, l, u, x, xp, z, y, reinterpret_cast<SmallOut*>(out_dev)); \
     } while (0)
 #define QPS_SMALL2(THN, IDX) do { if (lm) QPS_SMALL(THN, IDX, 1); else QPS_SMALL(THN, IDX, 0); } while (0)

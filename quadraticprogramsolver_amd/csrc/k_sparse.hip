@@ -846,7 +846,7 @@ template <typename T> struct SparseSolver : SolverBase {
             info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
             info->numRefactor = nref; info->cgIterations = (int)cg_total; info->rhoFinal = rho; info->rhoProposed = rhorho;
             info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = tref;
-            info->trsvBlock = 0; info->sweepVariant = 0;
+            info->trsvBlock = 0; info->sweepVariant = 0; info->sweepGaveUp = 0; info->reserved1 = 0;
             info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
         }
     }

@@ -21,11 +21,24 @@
 //     polls the granules of the previous block (every workgroup needs all nb values, produced four per workgroup), unpacks them into
 //     LDS and raises the LDS flag the streaming waves wait on before their last tile of the block row.
 // The epoch is a per-launch argument that only ever grows, so no word has to be cleared between launches and a launch that gave up
-// leaves nothing behind.  Every spin is bounded: a courier that waited `spin_limit` polls sets `abort_word`, every courier checks that word
-// while it spins, and the launch drains with garbage in `out`; the host sees the word at its next read-back, rebuilds the plain (not
-// pre-multiplied) sweep matrix, repeats the solve on the one-launch-per-phase substitution and keeps the handle there (qps_capi.hip).
-// Seen in practice when two handles run these launches at the same time from two host threads (tests/test_gpu_trsv_blocked.py).
+// leaves nothing behind.
+//
+// Co-residency.  The hand-offs need all 256 workgroups of a launch on the chip at once.  That is GUARANTEED, not hoped for:
+//   * trsv_blocked_supported() admits the kernel on a device only when that device has >= 256 CUs and
+//     hipOccupancyMaxActiveBlocksPerMultiprocessor says a workgroup with its 144 KiB of LDS fits a CU (facts cached per device ordinal);
+//   * every other kernel of the library terminates without waiting for another launch, so it can only delay these workgroups;
+//   * the one thing that could starve a launch for good is a SECOND launch of this kernel holding some of the CUs while waiting for
+//     its own missing workgroups.  SweepGate rules that out inside a process: all blocked-sweep launches of a device are chained
+//     across streams (the pair forward + backward is enqueued under a per-device mutex; a pair that follows a pair of ANOTHER stream
+//     first waits -- hipStreamWaitEvent -- for an event recorded behind that one), so at most one of them is ever on the chip.  A handle
+//     alone on its device pays one uncontended mutex per pair and no event.
+// The bounded spin stays as a backstop for what the process cannot see (another PROCESS running the same kernel on the card): a courier
+// that waited `spin_limit` polls sets `abort_word`, every courier checks that word while it spins, and the launch drains with garbage in
+// `out`; the host sees the word at its next read-back, repeats that solve on the one-launch-per-phase substitution (qps_info.sweepGaveUp
+// counts it) and tries the blocked sweeps again at its next solve (qps_capi.hip).
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "qps_kernels.h"
 #include "wave_reduce.h"
@@ -228,12 +241,47 @@ __global__ __launch_bounds__(STREAM + 64) void k_trsv_blocked(const T* __restric
     }
 }
 
-int device_cus() {
-    static const int cus = [] { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0; return pr.multiProcessorCount; }();
-    return cus;
+// Per-device facts, keyed by device ordinal (a process may hold handles on several devices, include/qps.h:19): 0 = not asked yet,
+// 1 = a launch of 256 workgroups with 144 KiB of LDS each is co-resident on this device, 2 = it is not.
+std::atomic<int> g_resident[kMaxDevices];
+bool launch_is_co_resident(int dev) {
+    if (dev < 0 || dev >= kMaxDevices) return false;
+    int v = g_resident[dev].load(std::memory_order_acquire);
+    if (v == 0) {
+        int per_cu = 0;
+        const void* kern = reinterpret_cast<const void*>(k_trsv_blocked<double, 512, false, 1>);   // 576 threads, the largest LDS request
+        const bool attr = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+        const bool occ = attr && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512 + 64, (size_t)144 * 1024) == hipSuccess && per_cu >= 1;
+        v = (occ && device_cu_count(dev) >= TBG) ? 1 : 2;
+        (void)hipGetLastError();
+        g_resident[dev].store(v, std::memory_order_release);
+    }
+    return v == 1;
 }
 
+// All blocked-sweep launches of one device in one chain (see the header comment).
+struct SweepGate { std::mutex mu; hipStream_t last = nullptr; hipEvent_t ev = nullptr; };
+SweepGate g_gate[kMaxDevices];
+
 }  // namespace
+
+TrsvBlockedPair::TrsvBlockedPair(int device, hipStream_t st) : dev(device >= 0 && device < kMaxDevices ? device : 0), stream(st) {
+    SweepGate& gt = g_gate[dev];
+    gt.mu.lock();
+    if (gt.last && gt.last != st) {
+        // the previous pair went to another stream: order this one behind everything that stream holds (the pair included)
+        if (!gt.ev && hipEventCreateWithFlags(&gt.ev, hipEventDisableTiming) != hipSuccess) { gt.ev = nullptr; (void)hipGetLastError(); }
+        if (gt.ev && hipEventRecord(gt.ev, gt.last) == hipSuccess) (void)hipStreamWaitEvent(st, gt.ev, 0);
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize(gt.last); }      // no event to be had: wait on the host instead
+    }
+}
+TrsvBlockedPair::~TrsvBlockedPair() { SweepGate& gt = g_gate[dev]; gt.last = stream; gt.mu.unlock(); }
+void trsv_blocked_forget_stream(int device, hipStream_t st) {
+    if (device < 0 || device >= kMaxDevices) return;
+    SweepGate& gt = g_gate[device];
+    std::lock_guard<std::mutex> lk(gt.mu);
+    if (gt.last == st) gt.last = nullptr;      // the stream is idle (its owner synchronised it) and may be destroyed
+}
 
 // nb must be the width one row of 512 (256) threads covers with 16-byte loads; at least two blocks; operands fit the 160 KiB of LDS
 template <typename T> bool trsv_blocked_supported(int NP, int nb) {
@@ -244,7 +292,7 @@ template <typename T> bool trsv_blocked_supported(int NP, int nb) {
     const int nblk = (NP + nb - 1) / nb;
     if (nblk < 2 || NP < 2 * VN) return false;
     if ((size_t)nblk * nb * sizeof(T) > (size_t)144 * 1024) return false;
-    return device_cus() >= TBG;
+    return launch_is_co_resident(current_device());
 }
 template <typename T> int64_t trsv_blocked_pub_words(int NP) { return (int64_t)(sizeof(T) / 4) * NP; }
 
@@ -257,11 +305,12 @@ void trsv_blocked(hipStream_t st, bool bwd, const T* S, int64_t ld, int NP, int 
     static const unsigned spin_limit = [] { const char* e = getenv("QPS_SWEEP_SPIN_LIMIT"); return e ? (unsigned)atol(e) : 200000u; }();
     const LaunchTiming lt = g_launch_timing;
     g_launch_timing = LaunchTiming();
+    const int dev_ = current_device();
 #define QPS_TB(STREAM, BWDV, WIN)                                                                                                       \
     do {                                                                                                                                \
         auto kern = k_trsv_blocked<T, STREAM, BWDV, WIN>;                                                                               \
-        static bool attr_done = false;                                                                                                  \
-        if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr_done = true; } \
+        static PerDeviceOnce attr_done;   /* the attribute lives in the device's code object: once per device ordinal */                \
+        if (attr_done.first(dev_)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
         if (lt.start) hipExtLaunchKernelGGL(kern, dim3(TBG), dim3(STREAM + 64), lds, st, lt.start, lt.stop, 0, S, ld, NP, v, out, pub, (int64_t)NP, epoch, abort_word, spin_limit, mode); \
         else hipLaunchKernelGGL(kern, dim3(TBG), dim3(STREAM + 64), lds, st, S, ld, NP, v, out, pub, (int64_t)NP, epoch, abort_word, spin_limit, mode); \
     } while (0)

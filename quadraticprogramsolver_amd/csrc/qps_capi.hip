@@ -14,10 +14,21 @@ using namespace qps;
 namespace qps {
 namespace {
 constexpr size_t kPinnedBytes = 512, kRecycleBlockMax = (size_t)512 << 20;   // blocks above 512 MiB go back to the driver (at most 4 x that per device stay cached, of 288 GB)
-constexpr int kMaxDevices = 64, kRecyclePerDevice = 4;
+constexpr int kRecyclePerDevice = 4;
 std::mutex g_res_mu;
 std::vector<HandleResources> g_res[kMaxDevices];
+std::atomic<int> g_cus[kMaxDevices];   // 0 = not asked yet
 }  // namespace
+int current_device() { int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; } return dev; }
+int device_cu_count(int device) {
+    if (device < 0 || device >= kMaxDevices) return 0;
+    int c = g_cus[device].load(std::memory_order_acquire);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); c = -1; }
+        g_cus[device].store(c, std::memory_order_release);
+    }
+    return c > 0 ? c : 0;
+}
 HandleResources acquire_resources(int device, size_t block_need) {
     HandleResources r;
     {
@@ -79,7 +90,8 @@ template <typename T> struct DenseSolver : SolverBase {
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     bool have_AA = false, factor_valid = false; double fac_rho = 0, fac_sigma = 0; int fac_nb = 0;
     int nb = 2048; int part_tiles = 0; int num_factorizations = 0;
-    // single-launch blocked sweeps (k_trsv_blocked.hip): hand-off granules, launch epoch, give-up word; `blocked_off` after a launch gave up
+    // single-launch blocked sweeps (k_trsv_blocked.hip): hand-off granules, launch epoch, give-up word; `blocked_off` while the solve whose
+    // launch gave up is being repeated on the multi-launch substitution (the next solve tries the blocked sweeps again)
     unsigned long long* pub = nullptr; unsigned* abort_dev = nullptr; unsigned sweep_epoch = 0; bool blocked_off = false, fac_premul = false;
     bool use_blocked() const { return !blocked_off && trsv_blocked_supported<T>(NP, nb); }
     // hipGraph replay of runs of plain iterations (no check, no rho switch) for problems small enough to be launch bound
@@ -172,6 +184,7 @@ template <typename T> struct DenseSolver : SolverBase {
     ~DenseSolver() override {
         (void)hipSetDevice(device);
         if (st) (void)hipStreamSynchronize(st);
+        if (st) trsv_blocked_forget_stream(device, st);   // the stream goes back to the pool (or is destroyed): the sweep gate must not record on it
         drop_graphs();
         prof.release_events();
         res.block = arena.base; res.block_bytes = arena.bytes; arena.base = nullptr;
@@ -236,8 +249,9 @@ template <typename T> struct DenseSolver : SolverBase {
         }
         factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb; fac_premul = use_blocked();
     }
-    // Did a blocked-sweep launch give up waiting (workgroups not co-resident, e.g. a card shared with another process)?  Then the iterates
-    // are garbage: the handle drops to the multi-launch sweeps for good and the caller repeats its work.  Synchronises the stream.
+    // Did a blocked-sweep launch give up waiting (its workgroups were not co-resident: only another PROCESS running the same kernel on the card
+    // can do that, launches of this process are chained by the sweep gate)?  Then the iterates are garbage: the caller repeats its work on the
+    // multi-launch sweeps (`blocked_off` until the next solve / linsys_init).  Synchronises the stream.
     bool sweep_gave_up(bool fetched = false) {
         if (!fac_premul) return false;
         unsigned* h = reinterpret_cast<unsigned*>(res_host + 14);
@@ -275,6 +289,7 @@ template <typename T> struct DenseSolver : SolverBase {
                 HIPC(hipMemsetAsync(pub, 0, sizeof(unsigned long long) * (size_t)trsv_blocked_pub_words<T>(NP), st));
                 sweep_epoch = 0;
             }
+            TrsvBlockedPair gate(device, st);   // never two of these persistent launches on the chip at once (k_trsv_blocked.hip, "Co-residency")
             { ProfLaunchScope ps(prof, cat_fwd, sample_lvl(13)); trsv_blocked<T>(st, false, S, NP, NP, nb, tt, yv, pub, ++sweep_epoch, abort_dev); }
             { ProfLaunchScope ps(prof, cat_bwd, sample_lvl(21)); trsv_blocked<T>(st, true, S, NP, NP, nb, yv, xx, pub, ++sweep_epoch, abort_dev); }
             return;
@@ -315,6 +330,16 @@ template <typename T> struct DenseSolver : SolverBase {
 
     void solve(double* xh, const qps_params& p, qps_info* info) override {
         HIPC(hipSetDevice(device));
+        blocked_off = false;                  // a handle whose launch gave up once tries the blocked sweeps again at every new solve
+        int gave_up = 0; double t_lost = 0;
+        const double t_begin = now_s();
+        while (solve_once(xh, p, info)) {     // true: a blocked-sweep launch gave up; x on the host is still the caller's
+            ++gave_up; t_lost = now_s() - t_begin;
+            const int lvl = prof.level; prof.reset(); prof.level = lvl;   // the aborted attempt's launches are not this solve's kernels
+        }
+        if (info) { info->sweepGaveUp = gave_up; info->reserved1 = 0; info->tLoop += t_lost; }   // the repeated work is loop time
+    }
+    bool solve_once(double* xh, const qps_params& p, qps_info* info) {
         if (p.linsys != QPS_LINSYS_AUTO && p.linsys != QPS_LINSYS_CHOLESKY)
             throw QpsError(QPS_ERR_UNSUPPORTED, "dense handles offer QPS_LINSYS_CHOLESKY only (qps_create_csc with dense_path = 0 for the CG and the sparse L D L' plugins)");
         const double t0 = now_s();
@@ -370,7 +395,7 @@ template <typename T> struct DenseSolver : SolverBase {
                 info->polishFlag = prs.flag; info->polishIterations = prs.minresIterations; info->tPolish = prs.seconds;
                 info->trsvBlock = nb; info->sweepVariant = 4;
             }
-            return;
+            return false;
         }
         const bool fused = pass_slabs > 0 && p.loopVariant != 1;
         int rhs_slabs = 0;   // z = y = 0: A'(rho z - y) = 0, no slab to add for the first right-hand side
@@ -448,14 +473,14 @@ template <typename T> struct DenseSolver : SolverBase {
                 HIPC(hipMemcpyAsync(res_host, res_dev, 15 * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPC(hipStreamSynchronize(st));
                 prof.harvest();
-                if (sweep_gave_up(true)) { solve(xh, p, info); return; }                                // x on the host is still the caller's
+                if (sweep_gave_up(true)) return true;
                 resP = res_host[0]; resD = res_host[1]; rhorho = res_host[4]; convFlag = (int)res_host[5];
                 if (convFlag != QPS_CONV_NUM_ITR) break;                                            // :66-68
             }
         }
         HIPC(hipStreamSynchronize(st));
         prof.harvest();
-        if (sweep_gave_up()) { solve(xh, p, info); return; }
+        if (sweep_gave_up()) return true;
         const double t2 = now_s();
         PolishReport pr;
         if (p.polish) polish_dense<T>(st, n, m, NP, MP, P, A, q, l, u, y, x, part, p, &pr);        // SolveQuadraticProgram.m:289-325
@@ -467,6 +492,7 @@ template <typename T> struct DenseSolver : SolverBase {
             info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
             info->trsvBlock = nb; info->sweepVariant = sweep_variant();
         }
+        return false;
     }
     void polish(double* xh, const double* yh, const qps_params& p, qps_polish_report* rep) override {
         HIPC(hipSetDevice(device));
@@ -488,6 +514,7 @@ template <typename T> struct DenseSolver : SolverBase {
         HIPC(hipSetDevice(device));
         if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "dense handles support QPS_LINSYS_CHOLESKY only");
         nb = pick_nb(nbreq, NP, sweep_fused_supported<T>(NP));
+        blocked_off = false;
         factorize(rho, sigma, true);
     }
     void linsys_solve(const double* xh, const double* zh, const double* yh, double rho, double sigma, int changed,
@@ -511,6 +538,7 @@ struct BatchSolverBase {
     int device = 0; int64_t n = 0, m = 0; int count = 0; std::string err; Profiler prof;
     virtual ~BatchSolverBase() {}
     virtual void solve_batch(double* x, const qps_params& p, qps_info* infos) = 0;
+    virtual void get_dual(double* z, double* y) = 0;   // [count][m] each
 };
 
 template <typename T> struct BatchedDenseSolver : BatchSolverBase {
@@ -584,6 +612,13 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)rows * cols, hipMemcpyHostToDevice, st));
         import_colmajor<T>(st, stage, rows, rows, cols, d, NP);
         HIPC(hipStreamSynchronize(st));
+    }
+    void get_dual(double* zh, double* yh) override {
+        HIPC(hipSetDevice(device));
+        for (int b = 0; b < count && m > 0; ++b) {
+            if (zh) { convert_back<T>(st, z + (int64_t)b * MP, stage, m); HIPC(hipMemcpyAsync(zh + (int64_t)b * m, stage, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
+            if (yh) { convert_back<T>(st, y + (int64_t)b * MP, stage, m); HIPC(hipMemcpyAsync(yh + (int64_t)b * m, stage, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, st)); HIPC(hipStreamSynchronize(st)); }
+        }
     }
     void load_problem(int b, const double* Ph, const double* Ah, const double* qh, const double* lh, const double* uh) {
         put_matrix(Ph, (int)n, (int)n, P + (int64_t)b * NP * NP);
@@ -802,6 +837,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 in.tSetup = t1 - t0; in.tLoop = t2 - t1; in.tRefactor = tref[b];   // wall time of the whole batch
                 in.polishFlag = pol[b].flag; in.polishIterations = pol[b].minresIterations; in.tPolish = pol[b].seconds;
                 in.trsvBlock = nb; in.sweepVariant = (nblk == 1 && sweep_fused_supported<T>(NP)) ? 2 : (nblk == 1 ? 3 : 1);
+                in.sweepGaveUp = 0; in.reserved1 = 0;
             }
         }
     }
@@ -1044,7 +1080,10 @@ QPS_API int32_t qps_polish(qps_handle hh, double* x, const double* y, const qps_
 
 QPS_API int32_t qps_get_dual(qps_handle hh, double* z, double* y) {
     Handle* h = reinterpret_cast<Handle*>(hh);
-    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (!h || (!h->impl && !h->fused_batch && h->batch.empty())) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (h->fused_batch) return guarded(h, [&] { h->fused_batch->get_dual(z, y); });
+    if (!h->impl)       // a batch of independent solvers: [count][m] like the fused batch
+        return guarded(h, [&] { for (size_t b = 0; b < h->batch.size(); ++b) h->batch[b]->get_dual(z ? z + (int64_t)b * h->m : nullptr, y ? y + (int64_t)b * h->m : nullptr); });
     return guarded(h, [&] { h->impl->get_dual(z, y); });
 }
 

@@ -14,7 +14,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace qps {
+
+// ---- per-device facts (qps_capi.hip).  A process may hold handles on several devices (include/qps.h:19), so nothing that
+// describes or configures a DEVICE is cached in a plain function-local static: it is keyed by the device ordinal. ----------------------
+constexpr int kMaxDevices = 64;
+int current_device();                 // hipGetDevice (the entry points of a handle make its device current first)
+int device_cu_count(int device);      // multiProcessorCount, asked once per ordinal
+// "has this been done on device d yet?" for per-device one-time settings such as hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+struct PerDeviceOnce {
+    std::atomic<unsigned char> done[kMaxDevices] = {};
+    bool first(int dev) { if (dev < 0 || dev >= kMaxDevices) return true; return done[dev].exchange(1, std::memory_order_acq_rel) == 0; }
+};
 
 // A launcher that finds a pending event pair here attaches it to its kernel dispatch (hipExtLaunchKernelGGL): the events then carry the
 // kernel's own begin / end timestamps -- what rocprofv3 reports -- instead of bracketing the launch from outside (+3-4 us of
@@ -160,8 +173,12 @@ template <typename T> void build_sweep_matrix(hipStream_t st, int NP, int nb, co
 // out = forward (bwd = false: rows of S left of and inside the diagonal block) or backward (bwd = true) sweep over the PREMULTIPLIED sweep
 // matrix with nb x nb blocks.  pub: trsv_blocked_pub_words<T>(NP) 64-bit words, zero-filled once (hand-off granules); epoch: a value that grows
 // with every launch on this pub buffer (never 0); abort_word: set to 1 by a launch that gave up waiting (its `out` is garbage then).
-template <typename T> bool trsv_blocked_supported(int NP, int nb);
+template <typename T> bool trsv_blocked_supported(int NP, int nb);   // on the CURRENT device (co-residency of the 256 workgroups checked per device)
 template <typename T> int64_t trsv_blocked_pub_words(int NP);
+// Scope around the launches of one forward + backward pair: chains the pair behind the previous blocked-sweep launches of the device
+// when those went to another stream, so that two of these persistent launches never share the chip (k_trsv_blocked.hip, "Co-residency").
+struct TrsvBlockedPair { int dev; hipStream_t stream; TrsvBlockedPair(int device, hipStream_t st); ~TrsvBlockedPair(); TrsvBlockedPair(const TrsvBlockedPair&) = delete; };
+void trsv_blocked_forget_stream(int device, hipStream_t st);   // a handle's stream is about to be recycled / destroyed (it is idle)
 template <typename T>
 void trsv_blocked(hipStream_t st, bool bwd, const T* S, int64_t ld, int NP, int nb, const T* v, T* out, unsigned long long* pub,
                   unsigned epoch, unsigned* abort_word, int mode = 0);

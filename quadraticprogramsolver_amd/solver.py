@@ -228,6 +228,14 @@ class QuadraticProgramBatch:
         _lib.check(_lib.lib().qps_solve_batch(self._h, _dp(X), C.byref(p), infos), self._h)
         return X, [ConvergenceFlag(i.convFlag) for i in infos], [i.as_dict() for i in infos]
 
+    def dual(self):
+        """(mZ, mY) [count x m] of the last solve (additive: the reference discards them)."""
+        Z = np.zeros((self.count, max(self.m, 1)))
+        Y = np.zeros((self.count, max(self.m, 1)))
+        if self.m > 0:
+            _lib.check(_lib.lib().qps_get_dual(self._h, _dp(Z), _dp(Y)), self._h)
+        return Z[:, :self.m], Y[:, :self.m]
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().qps_destroy(self._h)

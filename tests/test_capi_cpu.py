@@ -35,7 +35,7 @@ def test_default_params_are_the_reference_defaults(qps):
     assert (p.fctrRho, p.numItrConv, p.numItrPolish, p.epsMinres, p.numItrMinres) == (5.0, 25, 10, 1e-6, 500)
     assert (p.epsPcg, p.numItrPcg) == (1e-6, 1000)
     assert C.sizeof(_lib.QpsParams) == 8 * 4 + 9 * 8 + 4 * 4
-    assert C.sizeof(_lib.QpsInfo) == 4 * 4 + 7 * 8 + 2 * 4 + 8 + 2 * 4
+    assert C.sizeof(_lib.QpsInfo) == 4 * 4 + 7 * 8 + 2 * 4 + 8 + 4 * 4
     assert C.sizeof(_lib.QpsPolishReport) == 6 * 4 + 2 * 8
 
 
@@ -317,3 +317,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dp_, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("test infrastructure", ""), f"{f} mentions the oracle"
+
+
+def test_no_function_local_static_guards_per_device_hip_state():
+    """include/qps.h:19 promises handles on distinct devices of one process.  A function attribute (hipFuncSetAttribute) is a setting of ONE
+    device's code object and device properties describe ONE device: neither may hide behind a plain function-local `static` that remembers the
+    first device the process touched.  The library keys them by device ordinal (PerDeviceOnce, device_cu_count, launch_is_co_resident)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "quadraticprogramsolver_amd", "csrc")
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))):
+        text = open(path).read()
+        text_nc = re.sub(r"//[^\n]*", "", text)
+        lines = text_nc.split("\n")
+        for i, line in enumerate(lines):
+            if "hipFuncSetAttribute" in line:
+                ctx = " ".join(lines[max(0, i - 3):i + 1])
+                if ".first(" not in ctx and "launch_is_co_resident" not in " ".join(lines[max(0, i - 12):i + 1]):
+                    offenders.append(f"{os.path.basename(path)}:{i + 1}: hipFuncSetAttribute not behind a per-device once-flag")
+            if re.search(r"\bstatic\b(?!\s+(constexpr|inline|__device__|__global__|PerDeviceOnce))", line) and re.search(
+                    r"hipGetDeviceProperties|hipDeviceGetAttribute|hipOccupancyMaxActiveBlocks|multiProcessorCount|hipGetDevice\(", " ".join(lines[i:i + 3])):
+                offenders.append(f"{os.path.basename(path)}:{i + 1}: device query cached in a function-local static")
+            if re.search(r"\bstatic\s+bool\s+attr", line):
+                offenders.append(f"{os.path.basename(path)}:{i + 1}: static bool attr* flag")
+    assert not offenders, offenders

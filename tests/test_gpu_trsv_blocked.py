@@ -135,7 +135,7 @@ SCRIPT = '''
         for tag, kw in {"fixed": dict(numIterations=40, ϵAbs=0.0, ϵRel=0.0, ρ=0.1), "adaptive": dict(numIterations=3000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True)}.items():
             x = np.zeros(2100); info = {}
             prob.solve(x, trsvBlock=1024, info=info, **kw)
-            out[tag] = {"x": x.tolist(), "variant": info["sweepVariant"], "iterations": info["iterations"], "refactor": info["numRefactor"]}
+            out[tag] = {"x": x.tolist(), "variant": info["sweepVariant"], "iterations": info["iterations"], "refactor": info["numRefactor"], "gaveUp": info["sweepGaveUp"]}
         xx, zz = np.zeros(2100), np.zeros(900)
         prob.linsys_init(0.3, 1e-6, trsvBlock=1024)
         prob.linsys_solve(np.ones(2100), np.ones(900), -np.ones(900), 0.3, 1e-6, False, xx, zz)
@@ -145,13 +145,16 @@ SCRIPT = '''
 
 
 def test_blocked_sweep_gives_up_cleanly(gpu, tmp_path):
-    """A launch whose workgroups cannot all be resident must not hang: with the spin limit at zero every courier gives up at its first
-    unanswered poll, the launch drains, the host sees the give-up word at its next read-back, drops to the multi-launch substitution for good and
-    repeats the solve -- same answers as the normal run (and as the window knob, which only changes the prefetch depth)."""
+    """The backstop: a launch whose workgroups are not all resident (another PROCESS running the same kernel on the card -- launches of one
+    process are chained by the sweep gate) must not hang.  With the spin limit at zero every courier gives up at its first unanswered poll, the
+    launch drains, the host sees the give-up word at its next read-back and repeats THAT solve on the multi-launch substitution
+    (qps_info.sweepGaveUp = 1, sweepVariant = 1); the next solve tries the blocked sweeps again (and, with the limit still at zero, gives up
+    again) -- same answers as the normal run (and as the window knob, which only changes the prefetch depth)."""
     base = _child(SCRIPT, {}, tmp_path, "base.py")
-    assert base["fixed"]["variant"] == 5 and base["adaptive"]["variant"] == 5
+    assert base["fixed"]["variant"] == 5 and base["adaptive"]["variant"] == 5 and base["fixed"]["gaveUp"] == 0 and base["adaptive"]["gaveUp"] == 0
     gave_up = _child(SCRIPT, {"QPS_SWEEP_SPIN_LIMIT": "0"}, tmp_path, "giveup.py")
     assert gave_up["fixed"]["variant"] == 1 and gave_up["adaptive"]["variant"] == 1
+    assert gave_up["fixed"]["gaveUp"] == 1 and gave_up["adaptive"]["gaveUp"] == 1      # every solve retried the blocked sweeps first
     deep = _child(SCRIPT, {"QPS_SWEEP_WINDOW": "3"}, tmp_path, "deep.py")
     off = _child(SCRIPT, {"QPS_SWEEP_BLOCKED": "0"}, tmp_path, "off.py")
     assert deep["fixed"]["variant"] == 5 and off["fixed"]["variant"] == 1
@@ -163,10 +166,12 @@ def test_blocked_sweep_gives_up_cleanly(gpu, tmp_path):
 
 
 def test_blocked_sweeps_from_two_host_threads(gpu, c_oracle):
-    """Two handles driven from two host threads, both on the single-launch blocked sweeps: two persistent 256-workgroup launches share the
-    chip.  Either their workgroups are resident together (the hand-offs complete) or a launch gives up after its bounded spin and the handle
-    repeats the solve on the multi-launch substitution -- both ways every solve returns the oracle's iterates."""
+    """Two handles driven from two host threads, both on the single-launch blocked sweeps (SURVEY §8b "Threading", include/qps.h:19).  Two
+    persistent 256-workgroup launches must never hold parts of the chip while waiting for the rest: the per-device sweep gate chains the
+    pairs of the two streams, so EVERY solve of both threads stays on variant 5, none gives up, nobody waits for a spin limit (the whole
+    two-thread run takes seconds) -- and every solve returns the oracle's iterates."""
     import threading
+    import time
     cases = [GenerateDenseBenchmarkQP(2100, 400, stream=60, feasible=True), GenerateDenseBenchmarkQP(2500, 300, stream=61, feasible=True)]
     results = [None, None]
 
@@ -177,17 +182,20 @@ def test_blocked_sweeps_from_two_host_threads(gpu, c_oracle):
             for rep in range(4):
                 x = np.zeros(P.shape[0]); info = {}
                 prob.solve(x, numIterations=200, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, trsvBlock=1024, info=info)
-                outs.append((x, info["sweepVariant"]))
+                outs.append((x, info["sweepVariant"], info["sweepGaveUp"]))
             results[k] = outs
 
     threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    t0 = time.perf_counter()
     for t in threads:
         t.start()
     for t in threads:
         t.join(timeout=300)
+    elapsed = time.perf_counter() - t0
     for k in range(2):
         assert results[k] is not None
         xo, _ = c_oracle.solve(*cases[k], numIterations=200, epsAbs=0.0, epsRel=0.0, rho=0.1)
-        for x, variant in results[k]:
-            assert variant in (1, 5) and rel(x, xo) <= 1e-9
-        print("sweep variants of thread", k, [v for _, v in results[k]])
+        for x, variant, gave_up in results[k]:
+            assert variant == 5 and gave_up == 0 and rel(x, xo) <= 1e-9
+        print("sweep variants of thread", k, [v for _, v, _ in results[k]])
+    assert elapsed < 5.0, elapsed          # 2 x 4 solves of 200 iterations incl. handle creation and factorisation; a give-up alone used to cost 0.4 s
