@@ -179,6 +179,10 @@ int32_t qps_get_dual(qps_handle h, double *z_out, double *y_out);
 int32_t qps_linsys_init(qps_handle h, double rho, double sigma, int32_t linsys, int32_t trsvBlock);
 int32_t qps_linsys_solve(qps_handle h, const double *x, const double *z, const double *y, double rho, double sigma,
                          int32_t changed_rho, double *xx_out, double *zz_out);
+/* The keyword arguments of the CG plugins' Sol!  --  ItrSolCg! / LinOpCg! / LinMapsCg!(...; ϵPcg = 1e-6, numItrPcg = 1000)
+ * (LinearSystemSolvers.jl:125, :164, :207): inner tolerance (abstol of IterativeSolvers.cg!) and iteration cap used by the following
+ * qps_linsys_solve calls of a CG handle.  Accepted and without effect on the direct plugins (they have no inner iteration). */
+int32_t qps_linsys_set_cg(qps_handle h, double epsPcg, int32_t numItrPcg);
 
 /* Batch of `count` independent dense QPs of identical shape (BASELINE config 4).  Problem b uses
  * P + b*ldp*n ... i.e. arrays are stacked along a leading batch axis: P[count][n*n], A[count][m*n] (column-major

@@ -25,8 +25,8 @@ mutable struct QpsInfo
     rhoFinal::Float64; rhoProposed::Float64; resPrim::Float64; resDual::Float64
     tSetup::Float64; tLoop::Float64; tRefactor::Float64
     polishFlag::Int32; polishIterations::Int32; tPolish::Float64
-    trsvBlock::Int32; sweepVariant::Int32
-    QpsInfo() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1, 0, 0.0, 0, 0)
+    trsvBlock::Int32; sweepVariant::Int32; sweepGaveUp::Int32; reserved1::Int32
+    QpsInfo() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1, 0, 0.0, 0, 0, 0, 0)
 end
 
 struct HipCholInitT end;  const HipCholInit = HipCholInitT()      # dense reduced-form Cholesky on the device
@@ -36,6 +36,9 @@ struct HipCgT end;        const HipCg! = HipCgT()
 struct HipLdlInitT end;   const HipLdlInit = HipLdlInitT()        # sparse L D L' of the KKT matrix on the device: the counterpart of
 struct HipLdlT end;       const HipLdl! = HipLdlT()               # LaLdlInit/LaLdl!, QDLdlInit/QDLdl!, FacLdlInit/FacLdl! (LinearSystemSolvers.jl:16-107)
 const QPS_LINSYS_CHOLESKY = Int32(1); const QPS_LINSYS_CG = Int32(2); const QPS_LINSYS_KKT_LDL = Int32(3)
+# arithmetic type of the device-resident loop (qps_dtype): the boundary always carries Float64 arrays, `dtype = Float32` runs the loop in fp32
+_dtype(::Type{Float64}) = Int32(0)
+_dtype(::Type{Float32}) = Int32(1)
 
 function _check(status::Int32, h::Ptr{Cvoid} = C_NULL)
     status == 0 && return
@@ -44,7 +47,7 @@ function _check(status::Int32, h::Ptr{Cvoid} = C_NULL)
 end
 
 # SparseMatrixCSC{Float64,Int64} fields go through unchanged (colptr/rowval/nzval, index_base = 1)
-function _create(mP::SparseMatrixCSC{Float64,Int64}, vQ, mA::SparseMatrixCSC{Float64,Int64}, vL, vU; densePath::Bool, device = 0)
+function _create(mP::SparseMatrixCSC{Float64,Int64}, vQ, mA::SparseMatrixCSC{Float64,Int64}, vL, vU; densePath::Bool, device = 0, dtype::Type = Float64)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     n, m = size(mP, 1), size(mA, 1)
     GC.@preserve mP vQ mA vL vU begin
@@ -52,17 +55,17 @@ function _create(mP::SparseMatrixCSC{Float64,Int64}, vQ, mA::SparseMatrixCSC{Flo
             (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
              Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
             n, m, mP.colptr, mP.rowval, mP.nzval, mA.colptr, mA.rowval, mA.nzval, vQ, vL, vU,
-            Int32(1), Int32(densePath), Int32(0), Int32(device), h))
+            Int32(1), Int32(densePath), _dtype(dtype), Int32(device), h))
     end
     return h[]
 end
-function _create(mP::Matrix{Float64}, vQ, mA::Matrix{Float64}, vL, vU; densePath::Bool = true, device = 0)
+function _create(mP::Matrix{Float64}, vQ, mA::Matrix{Float64}, vL, vU; densePath::Bool = true, device = 0, dtype::Type = Float64)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     n, m = size(mP, 1), size(mA, 1)
     GC.@preserve mP vQ mA vL vU begin
         _check(ccall((:qps_create_dense, LIBQPS), Int32,
             (Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ref{Ptr{Cvoid}}),
-            n, m, mP, stride(mP, 2), mA, max(stride(mA, 2), 1), vQ, vL, vU, Int32(0), Int32(device), h))
+            n, m, mP, stride(mP, 2), mA, max(stride(mA, 2), 1), vQ, vL, vU, _dtype(dtype), Int32(device), h))
     end
     return h[]
 end
@@ -70,11 +73,16 @@ end
 function _solve!(vX::Vector{Float64}, mP, vQ, mA, vL, vU, densePath::Bool, linsys::Int32 = densePath ? QPS_LINSYS_CHOLESKY : QPS_LINSYS_CG;
     numIterations = 5000, œµAbs = 1e-6, œµRel = 1e-6, œÅ = 1, œÉ = 1e-6, Œ± = 1.6, Œ¥ = 1e-6, adptŒ°::Bool = false,
     fctrŒ° = 5, numItrConv = 25, numItrPolish = 10, œµMinres = 1e-6, numItrMinres = 500, info = nothing,
-    polish::Bool = false)   # polish = true: the polishing step of SolveQuadraticProgram.m:289-325 (the Julia loop reserves its kwargs unused)
-    h = _create(mP, Vector{Float64}(vQ), mA, Vector{Float64}(vL), Vector{Float64}(vU); densePath = densePath)
+    polish::Bool = false,   # polish = true: the polishing step of SolveQuadraticProgram.m:289-325 (the Julia loop reserves its kwargs unused)
+    œµPcg = 1e-6, numItrPcg = 1000,            # the CG plugins' own kwargs (LinearSystemSolvers.jl:125, :164, :207), used by (HipCgInit, HipCg!)
+    dtype::Type = Float64, trsvBlock = 0, loopVariant = 0, device = 0)   # additive (qps_params / qps_create_*): fp32 loop, sweep block, loop variant, GPU
+    if !densePath && !(mP isa SparseMatrixCSC && mA isa SparseMatrixCSC)     # the CG / L D L' plugins keep CSR storage: dense arrays are converted once
+        mP = SparseMatrixCSC{Float64, Int64}(sparse(mP)); mA = SparseMatrixCSC{Float64, Int64}(sparse(mA))
+    end
+    h = _create(mP, Vector{Float64}(vQ), mA, Vector{Float64}(vL), Vector{Float64}(vU); densePath = densePath, device = device, dtype = dtype)
     try
-        prm = QpsParams(numIterations, adptŒ°, numItrConv, numItrPolish, numItrMinres, linsys, 0, 0,
-                        œµAbs, œµRel, œÅ, œÉ, Œ±, Œ¥, fctrŒ°, œµMinres, 1e-6, 1000, 0, polish, 0)
+        prm = QpsParams(numIterations, adptŒ°, numItrConv, numItrPolish, numItrMinres, linsys, trsvBlock, 0,
+                        œµAbs, œµRel, œÅ, œÉ, Œ±, Œ¥, fctrŒ°, œµMinres, œµPcg, numItrPcg, loopVariant, polish, 0)
         inf = QpsInfo()
         GC.@preserve vX _check(ccall((:qps_solve, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{QpsParams}, Ref{QpsInfo}),
                                      h, vX, Ref(prm), inf), h)
@@ -99,10 +107,22 @@ function AutoLinearSystemPair(mP, mA)
     return kind == QPS_LINSYS_CG ? (HipCgInit, HipCg!) : (kind == QPS_LINSYS_KKT_LDL ? (HipLdlInit, HipLdl!) : (HipCholInit, HipChol!))
 end
 
-# Convenience form named in the project brief: SolveQuadraticProgram(P, q, A, l, u; ...) -> (x, flag)
-function SolveQuadraticProgram(mP, vQ, mA, vL, vU; kw...)
+# Convenience form named in the project brief: SolveQuadraticProgram(P, q, A, l, u; ...) -> (x, flag).  `linSolverMode` is the reference's own enum
+# (SolveQuadraticProgram.jl:11, spelled as there: modeAuto, modeItertaive, modeDirect) and is resolved as SolveQuadraticProgramRef! resolves it
+# (:135-151): modeItertaive -> matrix-free CG; modeDirect -> a factorisation (sparse L D L' of the KKT matrix for SparseMatrixCSC inputs, the dense
+# reduced Cholesky otherwise); modeAuto -> the size / density rule, evaluated by the library (qps_linsys_auto).  The rule was tuned for a CPU:
+# it sends every problem with more than 5000 rows to CG -- pass modeDirect to keep such a problem on the factorisation path.
+function SolveQuadraticProgram(mP, vQ, mA, vL, vU; linSolverMode::LinearSolverMode = modeAuto, kw...)
+    sparseIn = (mP isa SparseMatrixCSC) && (mA isa SparseMatrixCSC)
+    pair = if linSolverMode == modeItertaive
+        (HipCgInit, HipCg!)
+    elseif linSolverMode == modeDirect
+        sparseIn ? (HipLdlInit, HipLdl!) : (HipCholInit, HipChol!)
+    else
+        AutoLinearSystemPair(mP, mA)
+    end
     vX = zeros(size(mP, 1))
-    flag = SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, HipCholInit, HipChol!; kw...)
+    flag = SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, pair...; kw...)
     return vX, flag
 end
 
@@ -129,6 +149,20 @@ function (::HipLdlInitT)(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, œÅ, œ
 end
 (::HipLdlT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, œÅ, œÅ¬π, œÉ, numElements, numConstraints, changedŒ°) =
     HipChol!(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, œÅ, œÅ¬π, œÉ, numElements, numConstraints, changedŒ°)   # same qps_linsys_solve call
+# the matrix-free CG plugins' literal signature: LinOpCgInit / LinOpCg! (LinearSystemSolvers.jl:145-186; same shape as ItrSolCg* :110-142 and
+# LinMapsCg* :188-229).  Init keeps the CSC inputs as CSR on the device (the operator of :152-157 needs no factorisation); Sol! takes the
+# reference's kwargs `œµPcg, numItrPcg` (:164), runs the device-resident CG warm-started from the previous x~ (:179) and returns z~ = A x~ (:181).
+function (::HipCgInitT)(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, œÅ, œÅ¬π, œÉ, numElements, numConstraints)
+    h = _create(mP, Vector{Float64}(vQ), mA, zeros(numConstraints), zeros(numConstraints); densePath = false)
+    _check(ccall((:qps_linsys_init, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Float64, Int32, Int32), h, œÅ, œÉ, QPS_LINSYS_CG, 0), h)
+    return zeros(numElements), zeros(numConstraints), Any[HipLinSys(h)]
+end
+function (::HipCgT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, œÅ, œÅ¬π, œÉ, numElements, numConstraints, changedŒ°; œµPcg = 1e-6, numItrPcg = 1000)
+    h = tuSolver[1].h
+    _check(ccall((:qps_linsys_set_cg, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Int32), h, œµPcg, numItrPcg), h)
+    HipChol!(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, œÅ, œÅ¬π, œÉ, numElements, numConstraints, changedŒ°)   # same qps_linsys_solve call
+    return
+end
 
 function (::HipCholT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, œÅ, œÅ¬π, œÉ, numElements, numConstraints, changedŒ°)
     h = tuSolver[1].h
@@ -156,42 +190,59 @@ mutable struct ProxQPHip{T <: AbstractFloat}
     vX :: Vector{T}; vY :: Vector{T}; vZ :: Vector{T}; vS :: Vector{T}     # same field names as ProxQP.jl:9-18
     dataDim :: Int; numEq :: Int; numInEq :: Int
 end
-function ProxQPHip(mP :: Matrix{Float64}, vQ :: Vector{Float64}, mA :: Matrix{Float64}, vB :: Vector{Float64}, mC :: Matrix{Float64}, vD :: Vector{Float64})
+# `ProxQP{T <: AbstractFloat}` (ProxQP.jl:8): T is the arithmetic type of the device-resident loop (Float64 or Float32); the C ABI carries Float64
+# arrays either way, the state vectors come back as Vector{T}.
+_f64(v::AbstractVector) = Vector{Float64}(v)
+_f64(m::Matrix) = Matrix{Float64}(m)
+_f64(m::SparseMatrixCSC) = SparseMatrixCSC{Float64, Int64}(m)
+function ProxQPHip(mP :: Matrix{T}, vQ :: Vector{T}, mA :: Matrix{T}, vB :: Vector{T}, mC :: Matrix{T}, vD :: Vector{T}) where {T <: AbstractFloat}
     n, me, mi = size(mP, 1), size(mA, 1), size(mC, 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve mP vQ mA vB mC vD _check(ccall((:qps_proxqp_create_dense, LIBQPS), Int32,
+    P, q, A, b, C, d = _f64(mP), _f64(vQ), _f64(mA), _f64(vB), _f64(mC), _f64(vD)
+    GC.@preserve P q A b C d _check(ccall((:qps_proxqp_create_dense, LIBQPS), Int32,
         (Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Int32, Ref{Ptr{Cvoid}}),
-        n, me, mi, mP, n, vQ, mA, max(me, 1), vB, mC, max(mi, 1), vD, Int32(0), Int32(0), h))
+        n, me, mi, P, n, q, A, max(me, 1), b, C, max(mi, 1), d, _dtype(T), Int32(0), h))
     _check(ccall((:qps_proxqp_init_kkt, LIBQPS), Int32, (Ptr{Cvoid},), h[]), h[])          # ProxQP.jl:80-89 on the device
-    s = ProxQPHip{Float64}(h[], zeros(n), zeros(max(me, 1)), zeros(max(mi, 1)), zeros(max(mi, 1)), n, me, mi)
+    s = ProxQPHip{T}(h[], zeros(T, n), zeros(T, max(me, 1)), zeros(T, max(mi, 1)), zeros(T, max(mi, 1)), n, me, mi)
     finalizer(x -> ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), x.h), s)
+    _pull_state!(s)                                                                        # vX, vY, vS of the constructor (:80-89)
     return s
 end
 # SparseProxQP (ProxQP.jl:71, :95-115): the colptr / rowval / nzval fields as they are (1-based Int64); the matrices stay sparse on the device
-function ProxQPHip(mP :: SparseMatrixCSC{Float64, Int64}, vQ :: Vector{Float64}, mA :: SparseMatrixCSC{Float64, Int64}, vB :: Vector{Float64},
-                   mC :: SparseMatrixCSC{Float64, Int64}, vD :: Vector{Float64})
+function ProxQPHip(mP :: SparseMatrixCSC{T, Int64}, vQ :: Vector{T}, mA :: SparseMatrixCSC{T, Int64}, vB :: Vector{T},
+                   mC :: SparseMatrixCSC{T, Int64}, vD :: Vector{T}) where {T <: AbstractFloat}
     n, me, mi = size(mP, 1), size(mA, 1), size(mC, 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    vBp = isempty(vB) ? zeros(1) : vB; vDp = isempty(vD) ? zeros(1) : vD
-    GC.@preserve mP vQ mA vBp mC vDp _check(ccall((:qps_proxqp_create_csc, LIBQPS), Int32,
+    P, q, A, C = _f64(mP), _f64(vQ), _f64(mA), _f64(mC)
+    vBp = isempty(vB) ? zeros(1) : _f64(vB); vDp = isempty(vD) ? zeros(1) : _f64(vD)
+    GC.@preserve P q A vBp C vDp _check(ccall((:qps_proxqp_create_csc, LIBQPS), Int32,
         (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64},
          Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
-        n, me, mi, mP.colptr, mP.rowval, mP.nzval, vQ, mA.colptr, mA.rowval, mA.nzval, vBp, mC.colptr, mC.rowval, mC.nzval, vDp,
-        Int32(1), Int32(0), Int32(0), h))
+        n, me, mi, P.colptr, P.rowval, P.nzval, q, A.colptr, A.rowval, A.nzval, vBp, C.colptr, C.rowval, C.nzval, vDp,
+        Int32(1), _dtype(T), Int32(0), h))
     _check(ccall((:qps_proxqp_init_kkt, LIBQPS), Int32, (Ptr{Cvoid},), h[]), h[])          # ProxQP.jl:102-111 on the device
-    s = ProxQPHip{Float64}(h[], zeros(n), zeros(max(me, 1)), zeros(max(mi, 1)), zeros(max(mi, 1)), n, me, mi)
+    s = ProxQPHip{T}(h[], zeros(T, n), zeros(T, max(me, 1)), zeros(T, max(mi, 1)), zeros(T, max(mi, 1)), n, me, mi)
     finalizer(x -> ccall((:qps_destroy, LIBQPS), Int32, (Ptr{Cvoid},), x.h), s)
+    _pull_state!(s)
     return s
 end
-function SolveQuadraticProgram!(sQpProb :: ProxQPHip{Float64}; numIterations = 2000, œµAbs = 1e-7, œµRel = 1e-6, numItrConv = 50,
-                                œÅ = 1e2, œÉ = 1e-2, adptŒ° :: Bool = true, œÑ = 10.0)
+# device state -> sQpProb.vX / vY / vZ / vS (Float64 at the boundary, stored as T)
+function _pull_state!(sQpProb :: ProxQPHip{T}) where {T <: AbstractFloat}
+    x, y, z, sl = zeros(length(sQpProb.vX)), zeros(length(sQpProb.vY)), zeros(length(sQpProb.vZ)), zeros(length(sQpProb.vS))
+    GC.@preserve x y z sl _check(ccall((:qps_proxqp_get_state, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                                       sQpProb.h, x, y, z, sl), sQpProb.h)
+    sQpProb.vX .= x; sQpProb.vY .= y; sQpProb.vZ .= z; sQpProb.vS .= sl
+    return sQpProb
+end
+# same keyword names, defaults and `T`-typed scalars as ProxQP.jl:118
+function SolveQuadraticProgram!(sQpProb :: ProxQPHip{T}; numIterations :: Integer = 2000, œµAbs = T(1e-7), œµRel = T(1e-6), numItrConv :: Integer = 50,
+                                œÅ :: T = T(1e2), œÉ :: T = T(1e-2), adptŒ° :: Bool = true, œÑ :: T = T(10)) where {T <: AbstractFloat}
     prm = QpsProxQpParams(numIterations, numItrConv, adptŒ°, 0, œµAbs, œµRel, œÅ, œÉ, œÑ)
     rep = QpsProxQpReport()
     _check(ccall((:qps_proxqp_solve, LIBQPS), Int32, (Ptr{Cvoid}, Ref{QpsProxQpParams}, Ref{QpsProxQpReport}), sQpProb.h, Ref(prm), rep), sQpProb.h)
-    GC.@preserve sQpProb _check(ccall((:qps_proxqp_get_state, LIBQPS), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                                      sQpProb.h, sQpProb.vX, sQpProb.vY, sQpProb.vZ, sQpProb.vS), sQpProb.h)
-    return Dict{String, Real}("Converged" => rep.converged != 0, "Iterations" => rep.iterations, "œÅ" => rep.rho, "œÉ" => rep.sigma,
-                              "PrimalResidual" => rep.resPrim, "DualResidual" => rep.resDual)     # ProxQP.jl:127
+    _pull_state!(sQpProb)
+    return Dict{String, Real}("Converged" => rep.converged != 0, "Iterations" => rep.iterations, "œÅ" => T(rep.rho), "œÉ" => T(rep.sigma),
+                              "PrimalResidual" => T(rep.resPrim), "DualResidual" => T(rep.resDual))     # ProxQP.jl:127
 end
 
 

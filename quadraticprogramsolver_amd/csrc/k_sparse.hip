@@ -877,6 +877,7 @@ template <typename T> struct SparseSolver : SolverBase {
             rep->numActiveLower = pr.numLower; rep->numActiveUpper = pr.numUpper; rep->reserved0 = 0; rep->relres = pr.relres; rep->seconds = pr.seconds;
         }
     }
+    void linsys_set_cg(double eps, int itr) override { eps_pcg = eps; itr_pcg = itr; }             // LinOpCg!(...; ϵPcg, numItrPcg): LinearSystemSolvers.jl:164
     void linsys_init(double rho, double sigma, int linsys, int) override {
         HIPC(hipSetDevice(device));
         if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG && linsys != QPS_LINSYS_KKT_LDL)

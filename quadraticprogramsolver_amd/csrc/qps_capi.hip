@@ -1103,6 +1103,13 @@ QPS_API int32_t qps_linsys_solve(qps_handle hh, const double* x, const double* z
     return guarded(h, [&] { h->impl->linsys_solve(x, z, y, rho, sigma, changed, xx, zz); });
 }
 
+QPS_API int32_t qps_linsys_set_cg(qps_handle hh, double epsPcg, int32_t numItrPcg) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle");
+    if (std::isnan(epsPcg) || epsPcg < 0 || numItrPcg < 0) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "need epsPcg >= 0 and numItrPcg >= 0");
+    return guarded(h, [&] { h->impl->linsys_set_cg(epsPcg, numItrPcg); });
+}
+
 QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, const double* P, const double* A, const double* q,
                                        const double* l, const double* u, int32_t dtype, int32_t device, qps_handle* out) {
     if (!out) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "out handle pointer is NULL");

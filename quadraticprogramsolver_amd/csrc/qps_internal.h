@@ -161,6 +161,7 @@ struct SolverBase {
     virtual void get_dual(double* z, double* y) = 0;
     virtual void polish(double* x, const double* y, const qps_params& p, qps_polish_report* rep) { (void)x; (void)y; (void)p; (void)rep; throw QpsError(QPS_ERR_UNSUPPORTED, "polishing is not implemented for this handle type"); }
     virtual void linsys_init(double rho, double sigma, int linsys, int nb) = 0;
+    virtual void linsys_set_cg(double eps_pcg, int num_itr_pcg) { (void)eps_pcg; (void)num_itr_pcg; }   // direct plugins: no inner iteration
     virtual void linsys_solve(const double* x, const double* z, const double* y, double rho, double sigma, int changed,
                               double* xx, double* zz) = 0;
 };

@@ -151,7 +151,9 @@ class QuadraticProgram:
     def linsys_init(self, ρ, σ, trsvBlock=0):
         _lib.check(_lib.lib().qps_linsys_init(self._h, float(ρ), float(σ), self.linsys, int(trsvBlock)), self._h)
 
-    def linsys_solve(self, vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ):
+    def linsys_solve(self, vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ, ϵPcg=None, numItrPcg=None):
+        if ϵPcg is not None or numItrPcg is not None:                       # LinOpCg!(...; ϵPcg = 1e-6, numItrPcg = 1000), LinearSystemSolvers.jl:164
+            _lib.check(_lib.lib().qps_linsys_set_cg(self._h, float(1e-6 if ϵPcg is None else ϵPcg), int(1000 if numItrPcg is None else numItrPcg)), self._h)
         x, z, y = _vec(vX, "vX", self.n), _vec(vZ, "vZ", self.m), _vec(vY, "vY", self.m)
         xx = np.zeros(self.n)
         zz = np.zeros(max(self.m, 1))
@@ -266,8 +268,12 @@ def _make_pair(linsys: str, dtype: str = "f64"):
         vZZ = np.zeros(numConstraints)
         return vXX, vZZ, [prob]
 
-    def Sol(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ1, σ, numElements, numConstraints, changedΡ):
-        tuSolver[0].linsys_solve(vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ)
+    if linsys == "cg":
+        def Sol(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ1, σ, numElements, numConstraints, changedΡ, *, ϵPcg=1e-6, numItrPcg=1000):
+            tuSolver[0].linsys_solve(vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ, ϵPcg=ϵPcg, numItrPcg=numItrPcg)    # kwargs of LinearSystemSolvers.jl:164
+    else:
+        def Sol(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ1, σ, numElements, numConstraints, changedΡ):
+            tuSolver[0].linsys_solve(vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ)
 
     Init._qps_linsys = Sol._qps_linsys = linsys
     Init._qps_dtype = Sol._qps_dtype = dtype

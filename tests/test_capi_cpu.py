@@ -342,3 +342,114 @@ def test_no_function_local_static_guards_per_device_hip_state():
             if re.search(r"\bstatic\s+bool\s+attr", line):
                 offenders.append(f"{os.path.basename(path)}:{i + 1}: static bool attr* flag")
     assert not offenders, offenders
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The Julia binding cannot run in this pipeline (no Julia): guard it against drifting away from the C ABI by reading it.
+# _lib.py's Structures / argtypes are tied to include/qps.h by the tests above; here the .jl file is tied to _lib.py.
+# ---------------------------------------------------------------------------------------------------------------------
+JL = os.path.join(ROOT, "julia", "QuadraticProgramSolverHIP.jl")
+JL_SCALAR = {"Int32": C.c_int32, "Int64": C.c_int64, "Float64": C.c_double}
+
+
+def _jl_source():
+    return re.sub(r"#[^\n]*", "", open(JL, encoding="utf-8").read())
+
+
+def _jl_structs(src):
+    out = {}
+    for mm in re.finditer(r"(?:mutable\s+)?struct\s+(\w+)\s*\n(.*?)\nend", src, re.S):
+        fields = re.findall(r"(\w+)\s*::\s*(\w+)", mm.group(2))
+        out[mm.group(1)] = fields
+    return out
+
+
+def test_julia_structs_match_the_ctypes_structures():
+    from quadraticprogramsolver_amd import _lib
+    structs = _jl_structs(_jl_source())
+    pairs = {"QpsParams": _lib.QpsParams, "QpsInfo": _lib.QpsInfo, "QpsProxQpParams": _lib.QpsProxQpParams, "QpsProxQpReport": _lib.QpsProxQpReport,
+             "QpsPolishReport": _lib.QpsPolishReport}
+    for name, ct in pairs.items():
+        assert name in structs, name
+        jl = [(f, JL_SCALAR[t]) for f, t in structs[name]]
+        assert jl == [(f, t) for f, t in ct._fields_], (name, jl, ct._fields_)
+
+
+def _jl_ccalls(src):
+    """(symbol, return type, [argument types]) of every ccall((:sym, LIBQPS), Ret, (types...), args...)."""
+    calls = []
+    for mm in re.finditer(r"ccall\(\(:(\w+),\s*LIBQPS\),\s*(\w+),\s*\(", src):
+        i, depth, start = mm.end(), 1, mm.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        body = src[start:i - 1]
+        types, cur, d = [], "", 0
+        for ch in body:
+            if ch == "{":
+                d += 1
+            elif ch == "}":
+                d -= 1
+            if ch == "," and d == 0:
+                types.append(cur.strip()); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            types.append(cur.strip())
+        calls.append((mm.group(1), mm.group(2), types))
+    return calls
+
+
+def test_julia_ccall_signatures_match_the_ctypes_argtypes():
+    from quadraticprogramsolver_amd import _lib
+    L = _lib.lib()
+    structs = {"QpsParams": _lib.QpsParams, "QpsInfo": _lib.QpsInfo, "QpsProxQpParams": _lib.QpsProxQpParams, "QpsProxQpReport": _lib.QpsProxQpReport,
+               "QpsPolishReport": _lib.QpsPolishReport}
+
+    def ctype_of(t, sym, pos):
+        if t in JL_SCALAR:
+            return JL_SCALAR[t]
+        if t == "Ptr{Cvoid}":
+            return C.c_void_p
+        if t == "Ref{Ptr{Cvoid}}":
+            return C.POINTER(C.c_void_p)
+        mm = re.fullmatch(r"(?:Ptr|Ref)\{(\w+)\}", t)
+        assert mm, (sym, pos, t)
+        inner = mm.group(1)
+        if inner == "UInt8":                       # the batch's array of qps_info records is handed over as raw bytes
+            return getattr(L, sym).argtypes[pos]
+        return C.POINTER(structs[inner] if inner in structs else JL_SCALAR[inner])
+
+    calls = _jl_ccalls(_jl_source())
+    seen = set()
+    for sym, ret, types in calls:
+        fn = getattr(L, sym)
+        want = list(fn.argtypes)
+        got = [ctype_of(t, sym, k) for k, t in enumerate(types)]
+        assert got == want, (sym, types, want)
+        assert (ret == "Cstring") == (fn.restype is C.c_char_p) and (ret == "Int32") == (fn.restype is C.c_int32), (sym, ret)
+        seen.add(sym)
+    # every entry point a Julia user needs is bound (host-only analysis / profiling helpers are not part of the wrapper)
+    need = {"qps_create_dense", "qps_create_csc", "qps_solve", "qps_linsys_init", "qps_linsys_solve", "qps_linsys_set_cg", "qps_linsys_auto", "qps_destroy",
+            "qps_last_error", "qps_create_dense_batch", "qps_solve_batch", "qps_polish", "qps_proxqp_create_dense", "qps_proxqp_create_csc",
+            "qps_proxqp_init_kkt", "qps_proxqp_get_state", "qps_proxqp_solve"}
+    assert need <= seen, need - seen
+
+
+def test_julia_binding_covers_the_reference_interface():
+    """The names a user of the reference types: three plugin pairs callable with the literal plugin signature (LinearSystemSolvers.jl:16,28,145,164 --
+    the CG pair with its `ϵPcg, numItrPcg` kwargs), the modeAuto rule in the convenience form (SolveQuadraticProgram.jl:143-151), ProxQP{T} (ProxQP.jl:8)."""
+    src = _jl_source()
+    for pat in (r"function \(::HipCholInitT\)\(vX, mP, vQ, mA, ρ, ρ¹, σ, numElements, numConstraints\)",
+                r"function \(::HipCgInitT\)\(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, ρ, ρ¹, σ, numElements, numConstraints\)",
+                r"function \(::HipLdlInitT\)\(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, ρ, ρ¹, σ, numElements, numConstraints\)",
+                r"function \(::HipCgT\)\(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ; ϵPcg = 1e-6, numItrPcg = 1000\)",
+                r"function \(::HipCholT\)\(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ\)",
+                r"linSolverMode::LinearSolverMode = modeAuto", r"modeItertaive", r"AutoLinearSystemPair\(mP, mA\)",
+                r"ProxQPHip\{T <: AbstractFloat\}", r"where \{T <: AbstractFloat\}", r"_dtype\(::Type\{Float32\}\) = Int32\(1\)",
+                r"ϵPcg = 1e-6, numItrPcg = 1000", r"dtype::Type = Float64, trsvBlock = 0"):
+        assert re.search(pat, src), pat
+    # the kwargs of SolveQuadraticProgram.jl:15-17, names and defaults
+    for kw in ("numIterations = 5000", "ϵAbs = 1e-6", "ϵRel = 1e-6", "ρ = 1", "σ = 1e-6", "α = 1.6", "δ = 1e-6", "adptΡ::Bool = false", "fctrΡ = 5",
+               "numItrConv = 25", "numItrPolish = 10", "ϵMinres = 1e-6", "numItrMinres = 500"):
+        assert kw in src, kw
