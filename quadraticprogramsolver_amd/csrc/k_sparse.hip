@@ -112,6 +112,37 @@ constexpr int BCHUNK = 2048;          // non-zeros per task (512 threads x 4)
 constexpr int BTHREADS = 512;
 template <typename T> struct BlkOf { static constexpr int CB = (int)(57344 / sizeof(T)); };   // 56 KiB of x + 16 KiB of products: two workgroups per CU
 
+
+// four consecutive values as aligned 16-byte accesses, register to register (no pointer casts of local arrays: those end up in scratch)
+__device__ __forceinline__ void load4(const double* p, double (&o)[4]) { const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2); o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; }
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) { const float4 a = *reinterpret_cast<const float4*>(p); o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+__device__ __forceinline__ void store4(double* p, double a, double b, double c, double d) { *reinterpret_cast<double2*>(p) = make_double2(a, b); *reinterpret_cast<double2*>(p + 2) = make_double2(c, d); }
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ double2 vaxpy(double2 r, double beta, double2 u) { return make_double2(r.x + beta * u.x, r.y + beta * u.y); }
+__device__ __forceinline__ float4 vaxpy(float4 r, float beta, float4 u) { return make_float4(r.x + beta * u.x, r.y + beta * u.y, r.z + beta * u.z, r.w + beta * u.w); }
+__device__ __forceinline__ double2 vmask_tail(double2 v, int c, int cw) { return make_double2(c < cw ? v.x : 0.0, c + 1 < cw ? v.y : 0.0); }
+__device__ __forceinline__ float4 vmask_tail(float4 v, int c, int cw) { return make_float4(c < cw ? v.x : 0.f, c + 1 < cw ? v.y : 0.f, c + 2 < cw ? v.z : 0.f, c + 3 < cw ? v.w : 0.f); }
+__device__ __forceinline__ double2 vload_tail(const double* p, int c, int cw) { return make_double2(c < cw ? p[c] : 0.0, c + 1 < cw ? p[c + 1] : 0.0); }
+__device__ __forceinline__ float4 vload_tail(const float* p, int c, int cw) { return make_float4(c < cw ? p[c] : 0.f, c + 1 < cw ? p[c + 1] : 0.f, c + 2 < cw ? p[c + 2] : 0.f, c + 3 < cw ? p[c + 3] : 0.f); }
+__device__ __forceinline__ void vstore_tail(double* p, int c, int cw, double2 v) { if (c < cw) p[c] = v.x; if (c + 1 < cw) p[c + 1] = v.y; }
+__device__ __forceinline__ void vstore_tail(float* p, int c, int cw, float4 v) { if (c < cw) p[c] = v.x; if (c + 1 < cw) p[c + 1] = v.y; if (c + 2 < cw) p[c + 2] = v.z; if (c + 3 < cw) p[c + 3] = v.w; }
+
+// In-kernel stamps (diagnostic builds only: -DQPS_SPMV_STAMPS, tests/tools/gpu_c3_stamps.sh): thread 0 of every workgroup records s_memtime at
+// the phase boundaries of k_spmv_blk; qps_debug_spmv_stamps() hands the table to the host.  The product is built without it.
+#ifdef QPS_SPMV_STAMPS
+constexpr int STAMP_WGS = 1024, STAMP_SLOTS = 64;
+__device__ long long g_spmv_stamps[STAMP_WGS * STAMP_SLOTS];
+__device__ int g_spmv_stamp_rows = 0;
+#define QPS_STAMP(k)                                                                                                      \
+    do {                                                                                                                  \
+        const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                              \
+        if (threadIdx.x == 0 && wg_ < STAMP_WGS && (k) < STAMP_SLOTS && (g_spmv_stamp_rows == 0 || g_spmv_stamp_rows == nrows)) \
+            g_spmv_stamps[wg_ * STAMP_SLOTS + (k)] = (long long)__builtin_amdgcn_s_memtime();                             \
+    } while (0)
+#else
+#define QPS_STAMP(k) do { } while (0)
+#endif
+
 constexpr int BROWS = 1024;           // rows per task at most (their row pointers are staged in LDS)
 constexpr int BMAXT = 64;             // tasks per workgroup at most (their descriptors are staged in LDS)
 // Optional fusion of the CG direction update into the x-block load of the operator's first product:  u_new = r + beta u_old,
@@ -125,12 +156,13 @@ template <typename T> struct CgFuse {
 template <typename T, int LPR>        // LPR lanes add up one row segment (4 when a row holds <= ~8 non-zeros per block)
 __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, const int* __restrict__ task_ptr, const int4* __restrict__ tasks, int per,
                                                        const int* __restrict__ rp, const unsigned short* __restrict__ ci, const T* __restrict__ va,
+                                                       const int* __restrict__ lr_ptr, const int4* __restrict__ lr_desc,
                                                        const T* __restrict__ xin, T* __restrict__ partial, const CgState* __restrict__ st, CgFuse<T> fu) {
     if (st && st->done) return;
-    constexpr int CB = BlkOf<T>::CB, XPT = CB / BTHREADS;
-    __shared__ T xs[CB];
-    __shared__ T prod[BCHUNK];
-    __shared__ int rps[BROWS + 2];
+    constexpr int CB = BlkOf<T>::CB;
+    __shared__ __align__(16) T xs[CB + 8];                      // xs[CB] = 0: what an entry past the end of a task is multiplied by
+    __shared__ __align__(16) T prod[BCHUNK];
+    __shared__ int rps[BTHREADS + 2];
     __shared__ int4 meta[BMAXT];
     __shared__ double sh[BTHREADS / 64];
     const int tid = threadIdx.x, b = blockIdx.y;
@@ -156,83 +188,175 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
     }
     // this workgroup's tasks: a contiguous run [ts, te) of block b, so their descriptors come with one coalesced load and
     // no data load ever waits on a chain of dependent loads
-    const int ts = task_ptr[b] + blockIdx.x * per, te = min(task_ptr[b + 1], ts + per), nt = te - ts;
-    if (nt <= 0) return;
+    const int ts = task_ptr[b] + blockIdx.x * per, te = min(task_ptr[b + 1], ts + per), nt = max(te - ts, 0);
+    const int lr0 = lr_ptr[b] + blockIdx.x, lr1 = lr_ptr[b + 1];   // rows longer than a task: dealt round-robin over the block's workgroups
+    if (nt <= 0 && lr0 >= lr1) return;
+    QPS_STAMP(0);
+    // the descriptors of the first two tasks at workgroup-uniform addresses (scalar loads): their data loads leave together with the x block
+    // instead of behind the descriptor table's trip through LDS (one dependent memory round trip less in front of the first task).
+    // (A workgroup without tasks -- it has long rows only -- reads descriptor 0 of the table and never uses it.)
+    const int4 m0 = tasks[nt > 0 ? ts : 0], m1 = tasks[nt > 0 ? min(ts + 1, te - 1) : 0];
     int4 mt = make_int4(0, 0, 0, 0);
     if (tid < nt) mt = tasks[ts + tid];
     const int c0 = b * CB, cw = min(CB, ncols - c0);
-    T xr[XPT];                                                   // x block: all loads of a thread in flight together
+    // x block with 16-byte loads (the kernel is bound by the NUMBER of vector-memory instructions a CU can retire -- ~20-30 cycles each whatever
+    // their width, profiles/r03_b_c3_counters_before.json -- so every stream is read with the widest load its alignment allows)
+    using V = typename VecOf<T>::type;
+    constexpr int VN = VecOf<T>::N, XV = CB / (BTHREADS * VN);
+    static_assert(XV * BTHREADS * VN == CB, "x block = whole 16-byte loads per thread");
+    V xr[XV];
+    const bool xal = ((reinterpret_cast<uintptr_t>(xin + c0) & 15u) == 0) && (!fu.r || (((reinterpret_cast<uintptr_t>(fu.uold + c0) | reinterpret_cast<uintptr_t>(fu.unew + c0)) & 15u) == 0));   // (uniform)
+    if (xal) {
+        // every load first, unconditional, at a clamped position (vectors are allocated 64 elements past their length, so the vector that straddles the
+        // end of the last block is readable); elements past the block are zeroed afterwards and the direction update stores behind all loads
+        const int clast = ((cw + VN - 1) / VN - 1) * VN;
+        V uo[XV];
 #pragma unroll
-    for (int j = 0; j < XPT; ++j) { const int c = tid + BTHREADS * j; xr[j] = (c < cw) ? xin[c0 + c] : T(0); }
-    if (fu.r) {
+        for (int j = 0; j < XV; ++j) xr[j] = *reinterpret_cast<const V*>(xin + c0 + min((tid + BTHREADS * j) * VN, clast));
+        if (fu.r) {
 #pragma unroll
-        for (int j = 0; j < XPT; ++j) {
-            const int c = tid + BTHREADS * j;
-            if (c < cw) { xr[j] = xr[j] + beta * fu.uold[c0 + c]; if (blockIdx.x == 0) fu.unew[c0 + c] = xr[j]; }   // xin = r
+            for (int j = 0; j < XV; ++j) uo[j] = *reinterpret_cast<const V*>(fu.uold + c0 + min((tid + BTHREADS * j) * VN, clast));
+#pragma unroll
+            for (int j = 0; j < XV; ++j) xr[j] = vaxpy(xr[j], beta, uo[j]);                              // xin = r
+        }
+#pragma unroll
+        for (int j = 0; j < XV; ++j) xr[j] = vmask_tail(xr[j], (tid + BTHREADS * j) * VN, cw);
+        if (fu.r && blockIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < XV; ++j) { const int c = (tid + BTHREADS * j) * VN; if (c < cw) *reinterpret_cast<V*>(fu.unew + c0 + c) = xr[j]; }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) xr[j] = vload_tail(xin + c0, (tid + BTHREADS * j) * VN, cw);
+        if (fu.r) {
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                const int c = (tid + BTHREADS * j) * VN;
+                xr[j] = vaxpy(xr[j], beta, vload_tail(fu.uold + c0, c, cw));
+                if (blockIdx.x == 0) vstore_tail(fu.unew + c0, c, cw, xr[j]);
+            }
         }
     }
-    if (tid < nt) meta[tid] = mt;
-    __syncthreads();
+    QPS_STAMP(1);
     const int* rpb = rp + (int64_t)b * (nrows + 1);
     T* pout = partial + (int64_t)b * nrows;
-    // software pipeline, two tasks deep: (col, val) slices and row pointers of the next two tasks are in flight while one is reduced
-    struct Regs { int c[4]; T v[4]; int r[2]; int r0, r1, base, end; };
+    // software pipeline, two tasks deep: (col, val) slices and row pointers of the next two tasks are in flight while one is reduced.
+    // A thread owns FOUR CONSECUTIVE entries of a task: their 16-bit columns are one 8-byte load, their values one (fp32) or two (fp64) 16-byte
+    // loads -- the builder starts every task at a multiple of four entries (zero entries in between), so these loads are aligned.
+    struct Regs { uint2 cp; T v[4]; int r; int r0, r1, base, end; };   // fetched values stay RAW until their task: arithmetic on them here would wait for them here
     Regs RA, RB;
-    // UNCONDITIONAL loads at clamped positions (an entry past the slice is read from the slice's last entry and marked c = -1 afterwards): a
+    // UNCONDITIONAL loads at clamped positions (a thread past the slice re-reads the slice's first entries and marks them c = -1 afterwards): a
     // predicated load cannot be counted by the compiler, which then waits for every outstanding load (vmcnt(0)) before it touches ANY fetched
     // register -- the two-tasks-deep pipeline below waited for the slices it had just requested before reducing the one it had
-    auto fetch = [&](Regs& R, int i) {
-        const int4 m = meta[i];
+    auto fetch_desc = [&](Regs& R, const int4 m) {
         R.r0 = m.x; R.r1 = m.y; R.base = m.z; R.end = m.w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = R.base + tid + BTHREADS * j, kk = max(min(k, R.end - 1), 0);
-            const int cj = (int)ci[kk]; R.v[j] = va[kk];
-            R.c[j] = (k < R.end) ? cj : -1;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int r = R.r0 + tid + BTHREADS * j; R.r[j] = rpb[min(r, R.r1)]; }
+        const int k = R.base + 4 * tid;
+        const bool valid = k < R.end;
+        const int kk = valid ? k : R.base;
+        R.cp = *reinterpret_cast<const uint2*>(ci + kk);
+        load4(va + kk, R.v);
+        R.r = rpb[min(R.r0 + tid, R.r1)];                       // a task holds at most RPP * PG <= BTHREADS rows: one row pointer per thread
     };
-    auto process = [&](Regs& R, int inext) {
+    auto fetch = [&](Regs& R, int i) { fetch_desc(R, meta[i]); };
+    constexpr int RPP = BTHREADS / LPR;                         // rows per pass
+    constexpr int PG = 4, NIT = 4;                              // passes per task, entries per lane read without looking at the row length
+    // Every task issues the SAME number of vector-memory operations -- 3 or 4 loads, one store, no store inside a loop or a branch -- so that the
+    // compiler's in-order count of outstanding operations is exact and the wait in front of a task's data is for THAT data (fetched two tasks ago),
+    // not for whatever was requested last.  (With the row sums stored from inside the pass loop the count was unknown and every task waited for
+    // part of the fetch issued a thousand cycles earlier: the two-tasks-deep pipeline had an effective depth of one.)
+    T* const dump = partial + (int64_t)gridDim.y * nrows;       // 64 spare elements behind the partial sums: where a lane without a row stores
+    auto process = [&](Regs& R, int inext, int ti) {
+        (void)ti;
         const int r0 = R.r0, r1 = R.r1, base = R.base, end = R.end;
-        if (r1 - r0 == 1 && end - base > BCHUNK) {              // one long row of this block: strided walk + block reduction
-            fetch(R, min(inext, nt - 1));                        // (past the end: the last task again, never used -- no branch around the loads)
-            T s = T(0);
-            for (int k = base + tid; k < end; k += BTHREADS) s += va[k] * xs[ci[k]];
-            double d = (double)s;
-            d = wave_sum_all(d);
-            if ((tid & 63) == 0) sh[tid >> 6] = d;
-            __syncthreads();
-            if (tid == 0) { double tot = 0.0; for (int w = 0; w < BTHREADS / 64; ++w) tot += sh[w]; pout[r0] = (T)tot; }
-            __syncthreads();
-            return;
+        {   // four unconditional gathers in flight together (a select around a gather becomes a branch with a wait of its own)
+            const bool valid = base + 4 * tid < end;            // past the end: the zero slot of xs
+            const int q0 = valid ? (int)(R.cp.x & 0xffffu) : CB, q1 = valid ? (int)(R.cp.x >> 16) : CB;
+            const int q2 = valid ? (int)(R.cp.y & 0xffffu) : CB, q3 = valid ? (int)(R.cp.y >> 16) : CB;
+            const T x0 = xs[q0], x1 = xs[q1], x2 = xs[q2], x3 = xs[q3];
+            store4(prod + 4 * tid, R.v[0] * x0, R.v[1] * x1, R.v[2] * x2, R.v[3] * x3);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) prod[tid + BTHREADS * j] = (R.c[j] >= 0) ? R.v[j] * xs[R.c[j]] : T(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int i = tid + BTHREADS * j; if (i <= r1 - r0) rps[i] = R.r[j] - base; }
-        fetch(R, min(inext, nt - 1));                           // this register set is free again
-        __syncthreads();
-        const int lane = tid & (LPR - 1);
-        for (int i = tid / LPR; i < r1 - r0; i += BTHREADS / LPR) {
-            const int s0 = rps[i], s1 = rps[i + 1];
-            T s = T(0);
-            for (int k = s0 + lane; k < s1; k += LPR) s += prod[k];
-            s = (LPR == 8) ? oct_sum_all(s) : quad_sum_all(s);   // DPP: the LDS pipe is busy with the x gathers
-            if (lane == 0) pout[r0 + i] = s;
+        QPS_STAMP(3 + 4 * ti);
+        {
+            const int nr_ = r1 - r0;
+            if (tid < nr_) rps[tid] = R.r - base;
+            if (tid == 0) rps[nr_] = end - base;                // (the zero entries in front of the next task belong to the last row: harmless)
         }
+        fetch(R, min(inext, nt - 1));                           // this register set is free again (past the end: the last task again, never used)
         __syncthreads();
+        QPS_STAMP(4 + 4 * ti);
+        // Row sums.  The reads of a pass depend on each other (row pointers -> product segment -> sum): one pass at a time is a chain of LDS round
+        // trips (measured with in-kernel stamps: 2.4 k cycles of a 5.7 k-cycle task).  PG passes are walked together: all their row pointers first,
+        // then NIT entries per lane of every pass at clamped positions (no branch, all reads in flight), leftovers of longer rows in a loop, and
+        // ONE store per group: lane q of a row's lane group keeps the sum of pass q, so a wave writes four runs of consecutive rows at once.
+        const int nr = r1 - r0, lane = tid & (LPR - 1), row_in_pass = tid / LPR;
+        {
+            int s0[PG], s1[PG];
+#pragma unroll
+            for (int q = 0; q < PG; ++q) {
+                const int i = row_in_pass + q * RPP, ic = min(i, max(nr - 1, 0));
+                s0[q] = rps[ic]; s1[q] = rps[ic + 1];
+                if (i >= nr) s1[q] = s0[q];                      // no such row: an empty segment
+            }
+            T e[PG][NIT];
+#pragma unroll
+            for (int q = 0; q < PG; ++q)
+#pragma unroll
+                for (int t = 0; t < NIT; ++t) e[q][t] = prod[min(s0[q] + lane + LPR * t, BCHUNK - 1)];
+            T sum[PG];
+#pragma unroll
+            for (int q = 0; q < PG; ++q) {
+                sum[q] = T(0);
+#pragma unroll
+                for (int t = 0; t < NIT; ++t) sum[q] += (s0[q] + lane + LPR * t < s1[q]) ? e[q][t] : T(0);
+            }
+#pragma unroll
+            for (int q = 0; q < PG; ++q)
+                for (int k = s0[q] + lane + LPR * NIT; k < s1[q]; k += LPR) sum[q] += prod[k];     // rows with more than LPR * NIT entries in this block
+            T mine = T(0);
+#pragma unroll
+            for (int q = 0; q < PG; ++q) {
+                const T tot = (LPR == 8) ? oct_sum_all(sum[q]) : quad_sum_all(sum[q]);   // DPP: the LDS pipe is busy with the x gathers
+                mine = (lane == q) ? tot : mine;
+            }
+            const int i = row_in_pass + lane * RPP;
+            T* dst = (lane < PG && i < nr) ? pout + r0 + i : dump + (tid & 63);
+            *dst = mine;                                         // ONE unconditional store per task
+        }
+        QPS_STAMP(5 + 4 * ti);
+        __syncthreads();
+        QPS_STAMP(6 + 4 * ti);
     };
-    fetch(RA, 0);
-    fetch(RB, min(1, nt - 1));
+    fetch_desc(RA, m0);
+    fetch_desc(RB, m1);
 #pragma unroll
-    for (int j = 0; j < XPT; ++j) xs[tid + BTHREADS * j] = xr[j];
-    __syncthreads();                                            // xs complete
-    for (int i = 0; i < nt; i += 2) {
-        process(RA, i + 2);
-        if (i + 1 < nt) process(RB, i + 3);
+    for (int j = 0; j < XV; ++j) *reinterpret_cast<V*>(xs + (tid + BTHREADS * j) * VN) = xr[j];
+    if (tid < 8) xs[CB + tid] = T(0);
+    if (tid < nt) meta[tid] = mt;
+    __syncthreads();                                            // xs and the descriptor table complete
+    QPS_STAMP(2);
+    // pairs of tasks: inside this loop BOTH register sets are always walked, so the count of operations between a fetch and its use is the same on
+    // every path (with the second task behind an `if` the compiler assumed the path without it and waited for the fetch it had just issued)
+    int i = 0;
+    for (; i + 1 < nt; i += 2) {
+        process(RA, i + 2, i);
+        process(RB, i + 3, i + 1);
     }
+    if (i < nt) process(RA, i + 2, i);
+    // rows with more than BCHUNK entries in this block: strided walk by the whole workgroup + block reduction
+    for (int li = lr0; li < lr1; li += gridDim.x) {
+        const int4 d = lr_desc[li];
+        T s = T(0);
+        for (int k = d.y + tid; k < d.z; k += BTHREADS) s += va[k] * xs[ci[k]];
+        double dd = (double)s;
+        dd = wave_sum_all(dd);
+        __syncthreads();
+        if ((tid & 63) == 0) sh[tid >> 6] = dd;
+        __syncthreads();
+        if (tid == 0) { double tot = 0.0; for (int w = 0; w < BTHREADS / 64; ++w) tot += sh[w]; pout[d.x] = (T)tot; }
+    }
+    QPS_STAMP(63);
 }
+
 // out[row] = a0 * sum_b p0[b][row] + a1 * sum_b p1[b][row] + b0 v0[row] + b1 v1[row]; optional partials of dot(dotv, out)
 template <typename T>
 __global__ __launch_bounds__(256) void k_spmv_combine(int nrows, const T* __restrict__ p0, int n0, int64_t s0, T a0, const T* __restrict__ p1, int n1, int64_t s1_, T a1,
@@ -409,6 +533,7 @@ struct Csr {
     // column-blocked copy (k_spmv_blk): nblk CSR blocks back to back; used when `blocked`
     bool blocked = false; int ncols = 0, nblk = 0, wpb = 0; int* brp = nullptr; unsigned short* bci = nullptr; void* bva = nullptr;
     int* task_ptr = nullptr; int4* tasks = nullptr; int per = 1, lpr4 = 0; void* partial = nullptr;
+    int* lr_ptr = nullptr; int4* lr_desc = nullptr;   // rows with more than BCHUNK entries in one block: (row, first entry, end entry, 0), [nblk + 1] ranges
 };
 
 template <typename T> struct SparseSolver : SolverBase {
@@ -451,18 +576,46 @@ template <typename T> struct SparseSolver : SolverBase {
     void build_blocked(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
         constexpr int CB = BlkOf<T>::CB;
         const int nrows = M.nrows, nblk = (ncols + CB - 1) / CB;
+        // per block: entries per row, then the tasks (consecutive rows holding <= BCHUNK entries, <= BROWS - 1 rows; a longer row stands alone), then
+        // the offsets -- every TASK starts at a multiple of four entries (the kernel reads four consecutive entries per thread with aligned 8- and
+        // 16-byte loads); the gap in front of it holds zero entries, which the last row of the previous task sums up harmlessly
         std::vector<int> brp((size_t)nblk * (nrows + 1), 0);
         for (int r = 0; r < nrows; ++r)
             for (int k = rp[r]; k < rp[r + 1]; ++k) brp[(size_t)(ci[k] / CB) * (nrows + 1) + r + 1]++;
+        std::vector<int> tptr(nblk + 1, 0), lptr(nblk + 1, 0); std::vector<int4> tk, lr;
+        // lanes per row segment: 4 while a row holds <= ~8 entries per block on average, else 8; a task's rows are summed in ONE group of four passes
+        const int lpr4 = (M.nnz <= (int64_t)8 * nrows * nblk) ? 1 : 0;
+        const int max_rows = 4 * (BTHREADS / (lpr4 ? 4 : 8));        // 512 / 256 rows per task at most (k_spmv_blk: RPP * PG)
         int64_t run = 0;                                             // blocks back to back, rows in order inside a block
+        auto align4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
         for (int b = 0; b < nblk; ++b) {
             int* q_ = &brp[(size_t)b * (nrows + 1)];
-            int64_t acc = run;
-            for (int r = 0; r <= nrows; ++r) { const int cnt = q_[r]; q_[r] = (int)(acc += (r ? cnt : 0)); }
-            run = acc;
+            std::vector<int> cnt(q_ + 1, q_ + nrows + 1);
+            int64_t acc = align4(run); int start = 0; int64_t tnnz = 0;
+            q_[0] = (int)acc;
+            for (int r = 0; r < nrows; ++r) {
+                const bool alone = cnt[r] > BCHUNK;
+                if (r > start && (alone || tnnz + cnt[r] > BCHUNK || r - start >= max_rows)) {        // close [start, r)
+                    const int64_t e_ = align4(acc);
+                    tk.push_back(make_int4(start, r, q_[start], (int)e_));
+                    acc = e_; start = r; tnnz = 0;
+                }
+                q_[r] = (int)acc; acc += cnt[r]; tnnz += cnt[r];
+                if (alone) {                                         // a row longer than a task: summed by a whole workgroup behind the tasks
+                    const int64_t e_ = align4(acc);
+                    lr.push_back(make_int4(r, q_[r], (int)acc, 0));
+                    acc = e_; start = r + 1; tnnz = 0;
+                }
+            }
+            const int64_t e_ = align4(acc);
+            if (start < nrows) tk.push_back(make_int4(start, nrows, q_[start], (int)e_));
+            q_[nrows] = (int)e_;
+            run = e_;
+            tptr[b + 1] = (int)tk.size(); lptr[b + 1] = (int)lr.size();
         }
-        std::vector<unsigned short> bci((size_t)std::max<int64_t>(M.nnz, 1));
-        std::vector<T> bva((size_t)std::max<int64_t>(M.nnz, 1));
+        if (run + 64 > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 entries in the column-blocked copy");
+        std::vector<unsigned short> bci((size_t)run + 64, 0);
+        std::vector<T> bva((size_t)run + 64, T(0));
         {
             std::vector<int> pos((size_t)nblk * nrows);
             for (int b = 0; b < nblk; ++b) for (int r = 0; r < nrows; ++r) pos[(size_t)b * nrows + r] = brp[(size_t)b * (nrows + 1) + r];
@@ -472,28 +625,20 @@ template <typename T> struct SparseSolver : SolverBase {
                     bci[w_] = (unsigned short)(ci[k] - b * CB); bva[w_] = (T)va[k]; ++w_;
                 }
         }
-        std::vector<int> tptr(nblk + 1, 0); std::vector<int4> tk;
-        for (int b = 0; b < nblk; ++b) {
-            const int* q_ = &brp[(size_t)b * (nrows + 1)];
-            int start = 0;
-            for (int r = 0; r < nrows; ++r) {
-                if ((q_[r + 1] - q_[start] > BCHUNK || r - start >= BROWS - 1) && r > start) { tk.push_back(make_int4(start, r, q_[start], q_[r])); start = r; }
-                if (q_[r + 1] - q_[start] > BCHUNK) { tk.push_back(make_int4(r, r + 1, q_[r], q_[r + 1])); start = r + 1; }   // single long row
-            }
-            if (start < nrows) tk.push_back(make_int4(start, nrows, q_[start], q_[nrows]));
-            tptr[b + 1] = (int)tk.size();
-        }
-        M.ncols = ncols; M.nblk = nblk;
-        int maxt = 1; for (int b = 0; b < nblk; ++b) maxt = std::max(maxt, tptr[b + 1] - tptr[b]);
         static const int wgs_env = [] { const char* e = getenv("QPS_SPMV_WGS"); return e ? atoi(e) : 0; }();
         const int wgs = wgs_env > 0 ? wgs_env : 512;
+        M.ncols = ncols; M.nblk = nblk;
+        int maxt = 1; for (int b = 0; b < nblk; ++b) maxt = std::max(maxt, tptr[b + 1] - tptr[b]);
         M.wpb = std::max(1, std::min(maxt, (wgs + nblk - 1) / nblk));   // about two workgroups per CU over the launch
         M.wpb = std::max(M.wpb, (maxt + BMAXT - 1) / BMAXT);            // at most BMAXT tasks per workgroup
         M.per = (maxt + M.wpb - 1) / M.wpb;
-        M.lpr4 = (M.nnz <= (int64_t)8 * nrows * nblk) ? 1 : 0;          // short row segments: 4 lanes per row
+        M.lpr4 = lpr4;
         M.brp = dalloc<int>((int64_t)brp.size(), st); M.bci = dalloc<unsigned short>((int64_t)bci.size(), st); M.bva = dalloc<T>((int64_t)bva.size(), st);
         M.task_ptr = dalloc<int>(nblk + 1, st); M.tasks = dalloc<int4>((int64_t)tk.size() + 1, st);
-        M.partial = dalloc<T>((int64_t)nblk * nrows, st);
+        M.lr_ptr = dalloc<int>(nblk + 1, st); M.lr_desc = dalloc<int4>((int64_t)lr.size() + 1, st);
+        up->copy(M.lr_ptr, lptr.data(), sizeof(int) * lptr.size());
+        if (!lr.empty()) up->copy(M.lr_desc, lr.data(), sizeof(int4) * lr.size());
+        M.partial = dalloc<T>((int64_t)nblk * nrows + 64, st);          // + 64: the dump slots of lanes without a row
         up->copy(M.brp, brp.data(), sizeof(int) * brp.size());
         up->copy(M.bci, bci.data(), sizeof(unsigned short) * bci.size());
         up->copy(M.bva, bva.data(), sizeof(T) * bva.size());
@@ -650,7 +795,7 @@ template <typename T> struct SparseSolver : SolverBase {
         drop_graphs();
         if (cu2) (void)hipFree(cu2);
         for (Csr* M_ : {&A, &At, &P, &PA}) {
-            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial};
+            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial, M_->lr_ptr, M_->lr_desc};
             for (void* p : bp) if (p) (void)hipFree(p);
         }
         void* ptrs[] = {A.rp, A.ci, A.va, A.rb, At.rp, At.ci, At.va, At.rb, P.rp, P.ci, P.va, P.rb, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
@@ -679,9 +824,9 @@ template <typename T> struct SparseSolver : SolverBase {
 #define QPS_BLK(LPR)                                                                                                                        \
         do {                                                                                                                                \
             if (lt.start) hipExtLaunchKernelGGL((k_spmv_blk<T, LPR>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, lt.start, lt.stop, 0, M.nrows, M.ncols, M.task_ptr, \
-                                                M.tasks, M.per, M.brp, M.bci, static_cast<const T*>(M.bva), xin, static_cast<T*>(M.partial), stt, fu); \
+                                                M.tasks, M.per, M.brp, M.bci, static_cast<const T*>(M.bva), M.lr_ptr, M.lr_desc, xin, static_cast<T*>(M.partial), stt, fu); \
             else hipLaunchKernelGGL((k_spmv_blk<T, LPR>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, M.nrows, M.ncols, M.task_ptr, M.tasks, M.per, M.brp, M.bci, \
-                                    static_cast<const T*>(M.bva), xin, static_cast<T*>(M.partial), stt, fu);                                \
+                                    static_cast<const T*>(M.bva), M.lr_ptr, M.lr_desc, xin, static_cast<T*>(M.partial), stt, fu);             \
         } while (0)
         if (M.lpr4) QPS_BLK(4); else QPS_BLK(8);
 #undef QPS_BLK
@@ -1071,3 +1216,12 @@ SolverBase* make_sparse_solver(int device, int64_t n, int64_t m, int dtype, cons
 }
 
 }  // namespace qps
+
+#ifdef QPS_SPMV_STAMPS
+extern "C" __attribute__((visibility("default"))) int qps_debug_spmv_stamps(long long* out, int count, int filter_rows) {
+    using namespace qps;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_stamp_rows), &filter_rows, sizeof(int)) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spmv_stamps), sizeof(long long) * (size_t)count) != hipSuccess) return -2;
+    return 0;
+}
+#endif

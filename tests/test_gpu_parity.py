@@ -377,6 +377,46 @@ def test_cg_path_iterates_match_oracle(gpu, c_oracle, monkeypatch, pc, n, m, blo
             assert rel(x, xo) <= 1e-7 and rel(z, io["z"]) <= 1e-7 and rel(y, io["y"]) <= 1e-6
 
 
+def test_cg_path_blocked_spmv_with_long_empty_and_ragged_rows(gpu, c_oracle, monkeypatch):
+    """The column-blocked SpMV on a matrix built to hit every branch of its layout: rows with more entries in one column block than a task holds
+    (> 2048: a dense row across the wide block, dense columns of A = long rows of A'), rows of several hundred entries, a run of empty rows longer than
+    a task may hold, a narrow last column block, a row count that is no multiple of anything -- against the oracle's matrix-free CG at iterate level,
+    and the plugin pair against the host's products."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("QPS_SPMV_BLOCKED", "1")
+    rng = make_rng(91, 0)
+    n, m = 8000, 5003                                      # fp64: column blocks of 7168 -> A has blocks of 7168 + 832 columns, A' one block
+    A = sp.random(m, n, density=4e-3, random_state=np.random.RandomState(5), data_rvs=rng.standard_normal, format="lil")
+    A[17, :] = rng.standard_normal(n) * 0.1                # dense row: long in both column blocks
+    A[m - 1, 7168:] = rng.standard_normal(n - 7168) * 0.1  # long in the narrow block only (832 entries), last row of a ragged slice
+    A[100:900, :] = 0.0                                    # 800 empty rows in a row (a task holds at most 512 rows)
+    A[:, 4000:4003] = rng.standard_normal((m, 3)) * 0.05   # dense columns of A = long rows of A'
+    A = sp.csc_matrix(A)
+    M = sp.random(n, n, density=1e-3, random_state=np.random.RandomState(6), data_rvs=rng.standard_normal, format="csc")
+    P = (M.T @ M + 1e-2 * sp.eye(n)).tocsc()
+    q = rng.standard_normal(n); l = -rng.random(m); u = rng.random(m)
+    Ac, At, Pc = sp.csr_matrix(A), sp.csr_matrix(A.T), sp.csr_matrix(P)
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
+        x = np.zeros(n); info = {}
+        prob.solve(x, numIterations=10, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, ϵPcg=1e-13, numItrPcg=5000, info=info)
+        z, y = prob.dual()
+        xo, io = c_oracle.solve(P, q, A, l, u, numIterations=10, epsAbs=0.0, epsRel=0.0, rho=0.1, linsys=c_oracle.KIND_CG_MATFREE, epsPcg=1e-13, numItrPcg=5000)
+        assert rel(x, xo) <= 1e-7 and rel(z, io["z"]) <= 1e-7 and rel(y, io["y"]) <= 1e-6
+        # the products themselves: z~ = A x~ of the plugin pair, and the reported residuals (A x, P x, A'y of CheckConvergence)
+        prob.linsys_init(0.3, 1e-6)
+        xv, zv, yv = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(m)
+        xx, zz = np.zeros(n), np.zeros(m)
+        prob.linsys_solve(xv, zv, yv, 0.3, 1e-6, False, xx, zz, ϵPcg=1e-13, numItrPcg=5000)
+        assert np.abs(zz - Ac @ xx).max() <= 1e-11 * max(1.0, np.abs(zz).max())
+        rhs = 1e-6 * xv - q + At @ (0.3 * zv - yv)          # IterativeSolvers rule: ||r|| <= max(sqrt(eps) ||r0||, abstol) with a warm-started x0: a loose bound here
+        assert np.linalg.norm(Pc @ xx + 1e-6 * xx + 0.3 * (At @ (Ac @ xx)) - rhs) <= 1e-6 * np.linalg.norm(rhs)
+        xk = np.zeros(n); info = {}
+        prob.solve(xk, numIterations=25, ϵAbs=0.0, ϵRel=0.0, ρ=0.1, info=info)
+        zk, yk = prob.dual()
+        assert abs(info["resPrim"] - np.abs(Ac @ xk - zk).max()) <= 1e-9 * max(1.0, info["resPrim"])
+        assert abs(info["resDual"] - np.abs(Pc @ xk + q + At @ yk).max()) <= 1e-8 * max(1.0, info["resDual"])
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_cg_path_column_blocked_spmv_with_several_blocks(gpu, c_oracle, monkeypatch, dtype):
     """n = 9000, m = 16000: A has two column blocks, A' three (fp64: 7168 columns per block; one / two in fp32), so the partial sums per block,

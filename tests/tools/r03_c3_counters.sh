@@ -22,4 +22,4 @@ TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum T
 TCP_TCC_READ_REQ_LATENCY_sum TA_BUSY_avr TD_TD_BUSY_sum TA_TA_BUSY_sum
 GRBM_GUI_ACTIVE GRBM_COUNT
 GROUPS
-python tests/tools/pmc_counters_summary.py $O/c3_counters.json $files > $O/c3_counters.txt 2>&1; cat $O/c3_counters.txt | cut -c1-1500
+python tests/tools/pmc_counters_summary.py $O/c3_counters.json $files > $O/c3_counters.txt 2>&1; cut -c1-1500 $O/c3_counters.txt; rm -f $O/pass*_counters.csv
