@@ -357,6 +357,154 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
     QPS_STAMP(63);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Column-blocked SpMV, sliced form (round 3).  What the task form above costs per non-zero, measured (counters: profiles/r03_b_c3_counters_before.json;
+// in-kernel stamps: tests/tools/gpu_c3_stamps.sh): the x gather from LDS, the product written to LDS, the product read back from LDS by the lanes of
+// its row -- three LDS accesses per entry -- and two workgroup barriers per 2048 entries; a task lasts 5.7 k cycles of which 2.2 k are the row sums,
+// however the reads are batched: the LDS pipe is the shared resource the two workgroups of a CU fight for.
+//
+// Here a LANE owns a ROW, so a product never leaves its register: the only LDS access per entry is the gather of x.  To keep the loads coalesced the
+// rows of a column block are cut into slices of 64 (one per lane) and stored unit by unit: unit u of a slice holds entries u*E .. u*E+E-1 of all 64
+// rows, lane after lane (E = 2 in fp64, 4 in fp32: one 16-byte load of values and one 4- / 8-byte load of 16-bit columns per lane and unit).  A slice
+// is padded to the length of its longest row, so the rows are first sorted by their length in this block inside windows of SIGMA rows (sliced ELL with
+// a sorting window): the 64 rows of a slice then have nearly the same length and the padding stays small, while a row's partial sum still
+// lands within SIGMA rows of where its neighbours' do (the permutation is 16 bits per row and block).  Padding entries point at xs[CB] = 0 with value 0.
+// Rows with more than SLONG entries in one block (a dense constraint row) would pad their whole slice: they are left out of the slices and summed by a
+// wave each.  No barrier after the x block is in place, no reduction, no row pointers; the waves of a workgroup walk their slices independently.
+// (Tried and dropped: slices handed out one ticket at a time from a per-block atomic counter, to even out the workgroups' lifetimes -- ~600 waves
+// adding to one address serialise at ~80 ns each: 240 us per product instead of 27.  Non-temporal loads of the matrix: no difference.)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SIGMA = 2048;           // sorting window (rows)
+constexpr int SLONG = 96;             // more entries than this in one block: the row is summed by a wave of its own
+constexpr int SU = 4;                 // units of a slice in flight per batch
+struct SellDims { int nrows, ncols, nsl, wpb; };   // nsl = slices per column block
+template <typename T> struct SellOf;
+template <> struct SellOf<double> { static constexpr int E = 2; using CV = unsigned; };
+template <> struct SellOf<float> { static constexpr int E = 4; using CV = uint2; };
+__device__ __forceinline__ void sell_cols(unsigned p, int (&c)[2]) { c[0] = (int)(p & 0xffffu); c[1] = (int)(p >> 16); }
+__device__ __forceinline__ void sell_cols(uint2 p, int (&c)[4]) { c[0] = (int)(p.x & 0xffffu); c[1] = (int)(p.x >> 16); c[2] = (int)(p.y & 0xffffu); c[3] = (int)(p.y >> 16); }
+__device__ __forceinline__ void sell_vals(double2 v, double (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+__device__ __forceinline__ void sell_vals(float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+// wg_ptr [nblk][wpb + 1] slice range of every workgroup; sl_off [nblk * nsl + 1] first unit of a slice; perm [nblk * nsl * 64] row of a lane
+// relative to its window (0xffff: no row); cols / vals: unit-major, 64 lanes x E entries per unit; lr_ptr / lr_desc: long rows (row, first, end)
+template <typename T>
+__global__ __launch_bounds__(BTHREADS) void k_spmv_sell(SellDims a, const int* __restrict__ wg_ptr, const int* __restrict__ sl_off,
+                                                        const unsigned short* __restrict__ perm, const typename SellOf<T>::CV* __restrict__ cols,
+                                                        const typename VecOf<T>::type* __restrict__ vals, const unsigned short* __restrict__ lci,
+                                                        const T* __restrict__ lva, const int* __restrict__ lr_ptr, const int4* __restrict__ lr_desc,
+                                                        const T* __restrict__ xin, T* __restrict__ partial, const CgState* __restrict__ st, CgFuse<T> fu) {
+    if (st && st->done) return;
+    constexpr int CB = BlkOf<T>::CB, NW = BTHREADS / 64, E = SellOf<T>::E;
+    using V = typename VecOf<T>::type;
+    using CV = typename SellOf<T>::CV;
+    constexpr int VN = VecOf<T>::N, XV = CB / (BTHREADS * VN);
+    __shared__ __align__(16) T xs[CB + 8];                      // xs[CB] = 0: what a padding entry is multiplied by
+    __shared__ double sh[NW];
+    const int nrows = a.nrows;
+    const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: slice offsets stay scalar
+    T beta = T(0);
+    if (fu.r) {                                                 // same prologue as k_spmv_blk: u = r + beta u_old while the x block is loaded
+        if (fu.cur->done) { if (blockIdx.x == 0 && b == 0 && tid == 0) *fu.nxt = *fu.cur; return; }
+        double res2 = fu.cur->res2, prev2 = fu.cur->prev2; int iters = fu.cur->iters, done = 0;
+        if (!fu.first) {
+            double d = 0.0;
+            for (int i = tid; i < fu.nparts; i += BTHREADS) d += fu.part_rr[i];            // same order in every workgroup
+            d = wave_sum_all(d);
+            if (lane == 0) sh[wave] = d;
+            __syncthreads();
+            d = 0.0;
+            for (int w = 0; w < NW; ++w) d += sh[w];
+            prev2 = res2; res2 = d; iters += 1;
+            if (sqrt(d) <= fu.cur->tol || iters >= fu.cur->maxiter) done = 1;
+        }
+        if (blockIdx.x == 0 && b == 0 && tid == 0) { CgState s_ = *fu.cur; s_.res2 = res2; s_.prev2 = prev2; s_.iters = iters; s_.done = done; *fu.nxt = s_; }
+        if (done) return;
+        beta = (T)(res2 / prev2);
+    }
+    const int s_begin = wg_ptr[b * (a.wpb + 1) + blockIdx.x], s_end = wg_ptr[b * (a.wpb + 1) + blockIdx.x + 1];
+    const int lr0 = lr_ptr[b], lr1 = lr_ptr[b + 1];
+    if (s_begin >= s_end && lr0 + (int)blockIdx.x * NW >= lr1) return;   // (workgroup-uniform)
+    QPS_STAMP(0);
+    const int c0 = b * CB, cw = min(CB, a.ncols - c0);
+    const int64_t sb = (int64_t)b * a.nsl;
+    {
+        V xr[XV];
+        const bool xal = ((reinterpret_cast<uintptr_t>(xin + c0) & 15u) == 0) && (!fu.r || (((reinterpret_cast<uintptr_t>(fu.uold + c0) | reinterpret_cast<uintptr_t>(fu.unew + c0)) & 15u) == 0));   // (uniform)
+        if (xal) {
+            // every load first, unconditional, at a clamped position (vectors are allocated 64 elements past their length, so the vector that straddles
+            // the end of the last block is readable); elements past the block are zeroed afterwards and the direction update stores behind all loads
+            const int clast = ((cw + VN - 1) / VN - 1) * VN;
+            V uo[XV];
+#pragma unroll
+            for (int j = 0; j < XV; ++j) xr[j] = *reinterpret_cast<const V*>(xin + c0 + min((tid + BTHREADS * j) * VN, clast));
+            if (fu.r) {
+#pragma unroll
+                for (int j = 0; j < XV; ++j) uo[j] = *reinterpret_cast<const V*>(fu.uold + c0 + min((tid + BTHREADS * j) * VN, clast));
+#pragma unroll
+                for (int j = 0; j < XV; ++j) xr[j] = vaxpy(xr[j], beta, uo[j]);                          // xin = r
+            }
+#pragma unroll
+            for (int j = 0; j < XV; ++j) xr[j] = vmask_tail(xr[j], (tid + BTHREADS * j) * VN, cw);
+            if (fu.r && blockIdx.x == 0) {
+#pragma unroll
+                for (int j = 0; j < XV; ++j) { const int c = (tid + BTHREADS * j) * VN; if (c < cw) *reinterpret_cast<V*>(fu.unew + c0 + c) = xr[j]; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XV; ++j) xr[j] = vload_tail(xin + c0, (tid + BTHREADS * j) * VN, cw);
+            if (fu.r) {
+#pragma unroll
+                for (int j = 0; j < XV; ++j) {
+                    const int c = (tid + BTHREADS * j) * VN;
+                    xr[j] = vaxpy(xr[j], beta, vload_tail(fu.uold + c0, c, cw));
+                    if (blockIdx.x == 0) vstore_tail(fu.unew + c0, c, cw, xr[j]);
+                }
+            }
+        }
+        QPS_STAMP(1);
+#pragma unroll
+        for (int j = 0; j < XV; ++j) *reinterpret_cast<V*>(xs + (tid + BTHREADS * j) * VN) = xr[j];
+        if (tid < 8) xs[CB + tid] = T(0);
+    }
+    __syncthreads();                                            // xs complete; the only barrier of the kernel
+    QPS_STAMP(2);
+    T* pout = partial + (int64_t)b * nrows;
+    for (int s = s_begin + wave; s < s_end; s += NW) {
+        const int u0 = sl_off[sb + s], nu = sl_off[sb + s + 1] - u0;            // (scalar loads)
+        const unsigned pm = perm[(sb + s) * 64 + lane];
+        T acc = T(0);
+        for (int ub = 0; ub < nu; ub += SU) {
+            CV cp[SU]; V vv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {                      // UNCONDITIONAL loads (a unit past the slice re-reads its last one and is not used)
+                const int64_t at = ((int64_t)(u0 + min(ub + u, nu - 1))) * 64 + lane;
+                cp[u] = cols[at]; vv[u] = vals[at];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                if (ub + u < nu) {                              // (scalar condition: no vector-memory operation behind it)
+                    int c[E]; T v[E];
+                    sell_cols(cp[u], c); sell_vals(vv[u], v);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc += v[e] * xs[c[e]];
+                }
+            }
+        }
+        if (pm != 0xffffu) pout[(s >> 5) * SIGMA + (int)pm] = acc;              // 32 slices per sorting window
+        QPS_STAMP(3 + (s - s_begin) / NW);
+    }
+    // long rows of this block: one wave per row
+    for (int i = lr0 + blockIdx.x * NW + wave; i < lr1; i += a.wpb * NW) {
+        const int4 d = lr_desc[i];
+        T sum = T(0);
+        for (int k = d.y + lane; k < d.z; k += 64) sum += lva[k] * xs[lci[k]];
+        sum = wave_sum_all(sum);
+        if (lane == 0) pout[d.x] = sum;
+    }
+    QPS_STAMP(63);
+}
+
 // out[row] = a0 * sum_b p0[b][row] + a1 * sum_b p1[b][row] + b0 v0[row] + b1 v1[row]; optional partials of dot(dotv, out)
 template <typename T>
 __global__ __launch_bounds__(256) void k_spmv_combine(int nrows, const T* __restrict__ p0, int n0, int64_t s0, T a0, const T* __restrict__ p1, int n1, int64_t s1_, T a1,
@@ -534,6 +682,8 @@ struct Csr {
     bool blocked = false; int ncols = 0, nblk = 0, wpb = 0; int* brp = nullptr; unsigned short* bci = nullptr; void* bva = nullptr;
     int* task_ptr = nullptr; int4* tasks = nullptr; int per = 1, lpr4 = 0; void* partial = nullptr;
     int* lr_ptr = nullptr; int4* lr_desc = nullptr;   // rows with more than BCHUNK entries in one block: (row, first entry, end entry, 0), [nblk + 1] ranges
+    // sliced form (k_spmv_sell): units of 64 lanes x E entries; bci / bva then hold only the long rows' entries
+    bool sell = false; int nsl = 0; int* wg_ptr = nullptr; int* sl_off = nullptr; unsigned short* sl_perm = nullptr; void* s_cols = nullptr; void* s_vals = nullptr;
 };
 
 template <typename T> struct SparseSolver : SolverBase {
@@ -572,10 +722,113 @@ template <typename T> struct SparseSolver : SolverBase {
         return exec;
     }
 
+    // sliced form of the column-blocked copy (k_spmv_sell): rows sorted by their length in the block inside windows of SIGMA rows, slices of 64 rows
+    // padded to their longest row, stored unit by unit (64 lanes x E entries); rows longer than SLONG in a block go to the long-row list
+    bool build_sell(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
+        constexpr int CB = BlkOf<T>::CB, E = SellOf<T>::E;
+        const int nrows = M.nrows, nblk = (ncols + CB - 1) / CB;
+        const int nwin = (nrows + SIGMA - 1) / SIGMA;
+        const int nsl = (nwin - 1) * (SIGMA / 64) + ((nrows - (nwin - 1) * SIGMA) + 63) / 64;      // slices per block (only the last window is short)
+        if ((int64_t)nblk * nsl * 64 > 2000000000LL) return false;
+        // block-wise row pointers
+        std::vector<int> brp((size_t)nblk * (nrows + 1), 0);
+        for (int r = 0; r < nrows; ++r)
+            for (int k = rp[r]; k < rp[r + 1]; ++k) brp[(size_t)(ci[k] / CB) * (nrows + 1) + r + 1]++;
+        for (int b = 0; b < nblk; ++b) { int* q_ = &brp[(size_t)b * (nrows + 1)]; for (int r = 0; r < nrows; ++r) q_[r + 1] += q_[r]; }
+        // entries of block b, row r: column indices are sorted inside a row, so they are the run [first[b][r], first[b][r] + len) of the row
+        std::vector<int> first((size_t)nblk * nrows, 0);
+        for (int r = 0; r < nrows; ++r) {
+            int k = rp[r];
+            for (int b = 0; b < nblk; ++b) { first[(size_t)b * nrows + r] = k; k += brp[(size_t)b * (nrows + 1) + r + 1] - brp[(size_t)b * (nrows + 1) + r]; }
+        }
+        std::vector<int> sl_off((size_t)nblk * nsl + 1, 0), lptr(nblk + 1, 0); std::vector<int4> lr;
+        std::vector<unsigned short> perm((size_t)nblk * nsl * 64, (unsigned short)0xffff);
+        std::vector<unsigned short> cols, lci; std::vector<T> vals, lva;
+        cols.reserve((size_t)(M.nnz + M.nnz / 8)); vals.reserve((size_t)(M.nnz + M.nnz / 8));
+        int64_t units = 0;
+        std::vector<std::pair<int, int>> ord;                        // (length, row) of one window
+        for (int b = 0; b < nblk; ++b) {
+            const int* q_ = &brp[(size_t)b * (nrows + 1)];
+            for (int w = 0; w < nwin; ++w) {
+                const int r0 = w * SIGMA, r1 = std::min(nrows, r0 + SIGMA);
+                ord.clear();
+                for (int r = r0; r < r1; ++r) {
+                    const int L = q_[r + 1] - q_[r];
+                    if (L > SLONG) {                                 // summed by a wave of its own, not stored by a slice
+                        const int k0 = first[(size_t)b * nrows + r];
+                        lr.push_back(make_int4(r, (int)lci.size(), (int)lci.size() + L, 0));
+                        for (int k = 0; k < L; ++k) { lci.push_back((unsigned short)(ci[k0 + k] - b * CB)); lva.push_back((T)va[k0 + k]); }
+                        continue;
+                    }
+                    ord.emplace_back(L, r);
+                }
+                std::stable_sort(ord.begin(), ord.end(), [](const std::pair<int, int>& x_, const std::pair<int, int>& y_) { return x_.first > y_.first; });
+                const int wsl = (r1 - r0 + 63) / 64;                 // slices of this window (long rows leave lanes without a row at its end)
+                for (int sl = 0; sl < wsl; ++sl) {
+                    const int64_t g = (int64_t)b * nsl + (int64_t)w * (SIGMA / 64) + sl;
+                    sl_off[g] = (int)units;
+                    const int p0 = sl * 64;
+                    const int L = p0 < (int)ord.size() ? ord[p0].first : 0, nu = (L + E - 1) / E;
+                    for (int lane = 0; lane < 64; ++lane) if (p0 + lane < (int)ord.size()) perm[g * 64 + lane] = (unsigned short)(ord[p0 + lane].second - r0);
+                    const size_t base = cols.size();
+                    cols.resize(base + (size_t)nu * 64 * E, (unsigned short)CB); vals.resize(base + (size_t)nu * 64 * E, T(0));
+                    for (int lane = 0; lane < 64 && p0 + lane < (int)ord.size(); ++lane) {
+                        const int len = ord[p0 + lane].first, k0 = first[(size_t)b * nrows + ord[p0 + lane].second];
+                        for (int j = 0; j < len; ++j) {
+                            const size_t at = base + ((size_t)(j / E) * 64 + lane) * E + (j % E);
+                            cols[at] = (unsigned short)(ci[k0 + j] - b * CB); vals[at] = (T)va[k0 + j];
+                        }
+                    }
+                    units += nu;
+                    if (units > 30000000LL) return false;            // int32 unit offsets x 64 lanes: leave such matrices to the task form
+                }
+            }
+            lptr[b + 1] = (int)lr.size();
+        }
+        sl_off[(size_t)nblk * nsl] = (int)units;
+        static const int wgs_env = [] { const char* e = getenv("QPS_SPMV_WGS"); return e ? atoi(e) : 0; }();
+        const int wgs = wgs_env > 0 ? wgs_env : 512;
+        M.ncols = ncols; M.nblk = nblk; M.nsl = nsl;
+        M.wpb = std::max(1, std::min(nsl, wgs / nblk));              // floor: a launch of at most `wgs` workgroups is resident at once (2 per CU)
+        std::vector<int> wg_ptr((size_t)nblk * (M.wpb + 1), 0);
+        for (int b = 0; b < nblk; ++b) {                             // slice ranges of equal cost (units + a fixed part per slice)
+            const int* so = &sl_off[(size_t)b * nsl];
+            const int64_t tot = (int64_t)(so[nsl] - so[0]) + 2 * (int64_t)nsl;
+            int* wp = &wg_ptr[(size_t)b * (M.wpb + 1)];
+            int w = 1;
+            for (int sl = 0; sl < nsl; ++sl) {
+                const int64_t run_ = (int64_t)(so[sl + 1] - so[0]) + 2 * (int64_t)(sl + 1);
+                while (w < M.wpb && run_ * M.wpb >= tot * w) wp[w++] = sl + 1;
+            }
+            while (w <= M.wpb) wp[w++] = nsl;
+        }
+        cols.resize(cols.size() + 64 * E, (unsigned short)CB); vals.resize(vals.size() + 64 * E, T(0));   // a slice without units still reads one
+        lci.resize(lci.size() + 64, 0); lva.resize(lva.size() + 64, T(0));
+        M.s_cols = dalloc<unsigned short>((int64_t)cols.size(), st); M.s_vals = dalloc<T>((int64_t)vals.size(), st);
+        M.bci = dalloc<unsigned short>((int64_t)lci.size(), st); M.bva = dalloc<T>((int64_t)lva.size(), st);
+        M.sl_off = dalloc<int>((int64_t)sl_off.size(), st); M.sl_perm = dalloc<unsigned short>((int64_t)perm.size(), st);
+        M.wg_ptr = dalloc<int>((int64_t)wg_ptr.size(), st); M.lr_ptr = dalloc<int>(nblk + 1, st); M.lr_desc = dalloc<int4>((int64_t)lr.size() + 1, st);
+        M.partial = dalloc<T>((int64_t)nblk * nrows + 64, st);
+        up->copy(M.s_cols, cols.data(), sizeof(unsigned short) * cols.size());
+        up->copy(M.s_vals, vals.data(), sizeof(T) * vals.size());
+        up->copy(M.bci, lci.data(), sizeof(unsigned short) * lci.size());
+        up->copy(M.bva, lva.data(), sizeof(T) * lva.size());
+        up->copy(M.sl_off, sl_off.data(), sizeof(int) * sl_off.size());
+        up->copy(M.sl_perm, perm.data(), sizeof(unsigned short) * perm.size());
+        up->copy(M.wg_ptr, wg_ptr.data(), sizeof(int) * wg_ptr.size());
+        up->copy(M.lr_ptr, lptr.data(), sizeof(int) * lptr.size());
+        if (!lr.empty()) up->copy(M.lr_desc, lr.data(), sizeof(int4) * lr.size());
+        M.blocked = true; M.sell = true;
+        return true;
+    }
     // column-blocked copy for k_spmv_blk: per block a CSR with 16-bit local column indices + its task list
     void build_blocked(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
         constexpr int CB = BlkOf<T>::CB;
         const int nrows = M.nrows, nblk = (ncols + CB - 1) / CB;
+        {
+            const char* e = getenv("QPS_SPMV_SELL");                 // read per handle: 0 = the task form (k_spmv_blk)
+            if (!(e && atoi(e) == 0) && build_sell(M, ncols, rp, ci, va)) return;
+        }
         // per block: entries per row, then the tasks (consecutive rows holding <= BCHUNK entries, <= BROWS - 1 rows; a longer row stands alone), then
         // the offsets -- every TASK starts at a multiple of four entries (the kernel reads four consecutive entries per thread with aligned 8- and
         // 16-byte loads); the gap in front of it holds zero entries, which the last row of the previous task sums up harmlessly
@@ -795,7 +1048,7 @@ template <typename T> struct SparseSolver : SolverBase {
         drop_graphs();
         if (cu2) (void)hipFree(cu2);
         for (Csr* M_ : {&A, &At, &P, &PA}) {
-            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial, M_->lr_ptr, M_->lr_desc};
+            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial, M_->lr_ptr, M_->lr_desc, M_->wg_ptr, M_->sl_off, M_->sl_perm, M_->s_cols, M_->s_vals};
             for (void* p : bp) if (p) (void)hipFree(p);
         }
         void* ptrs[] = {A.rp, A.ci, A.va, A.rb, At.rp, At.ci, At.va, At.rb, P.rp, P.ci, P.va, P.rb, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
@@ -821,6 +1074,16 @@ template <typename T> struct SparseSolver : SolverBase {
     void spmv_blk(const Csr& M, const T* xin, const CgState* stt, CgFuse<T> fu = CgFuse<T>()) {
         const LaunchTiming lt = g_launch_timing;   // profiled launch: the dispatch's own begin / end timestamps (qps_kernels.h)
         g_launch_timing = LaunchTiming();
+        if (M.sell) {
+            const SellDims sd{M.nrows, M.ncols, M.nsl, M.wpb};
+            using CV = typename SellOf<T>::CV; using V = typename VecOf<T>::type;
+            if (lt.start) hipExtLaunchKernelGGL((k_spmv_sell<T>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, lt.start, lt.stop, 0, sd, M.wg_ptr, M.sl_off, M.sl_perm,
+                                                static_cast<const CV*>(M.s_cols), static_cast<const V*>(M.s_vals), M.bci, static_cast<const T*>(M.bva), M.lr_ptr, M.lr_desc, xin,
+                                                static_cast<T*>(M.partial), stt, fu);
+            else hipLaunchKernelGGL((k_spmv_sell<T>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, sd, M.wg_ptr, M.sl_off, M.sl_perm, static_cast<const CV*>(M.s_cols),
+                                    static_cast<const V*>(M.s_vals), M.bci, static_cast<const T*>(M.bva), M.lr_ptr, M.lr_desc, xin, static_cast<T*>(M.partial), stt, fu);
+            return;
+        }
 #define QPS_BLK(LPR)                                                                                                                        \
         do {                                                                                                                                \
             if (lt.start) hipExtLaunchKernelGGL((k_spmv_blk<T, LPR>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, lt.start, lt.stop, 0, M.nrows, M.ncols, M.task_ptr, \
@@ -1220,6 +1483,12 @@ SolverBase* make_sparse_solver(int device, int64_t n, int64_t m, int dtype, cons
 #ifdef QPS_SPMV_STAMPS
 extern "C" __attribute__((visibility("default"))) int qps_debug_spmv_stamps(long long* out, int count, int filter_rows) {
     using namespace qps;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (count < 0) {   // clear the table
+        void* p_ = nullptr;
+        if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_spmv_stamps)) != hipSuccess || hipMemset(p_, 0, sizeof(long long) * STAMP_WGS * STAMP_SLOTS) != hipSuccess) return -4;
+        return hipDeviceSynchronize() == hipSuccess ? 0 : -5;
+    }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_stamp_rows), &filter_rows, sizeof(int)) != hipSuccess) return -1;
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spmv_stamps), sizeof(long long) * (size_t)count) != hipSuccess) return -2;
     return 0;
