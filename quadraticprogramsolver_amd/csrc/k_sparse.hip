@@ -1483,11 +1483,10 @@ SolverBase* make_sparse_solver(int device, int64_t n, int64_t m, int dtype, cons
 #ifdef QPS_SPMV_STAMPS
 extern "C" __attribute__((visibility("default"))) int qps_debug_spmv_stamps(long long* out, int count, int filter_rows) {
     using namespace qps;
-    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    // (called between blocking qps_solve calls: the handle's stream is idle, nothing to wait for here)
     if (count < 0) {   // clear the table
-        void* p_ = nullptr;
-        if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_spmv_stamps)) != hipSuccess || hipMemset(p_, 0, sizeof(long long) * STAMP_WGS * STAMP_SLOTS) != hipSuccess) return -4;
-        return hipDeviceSynchronize() == hipSuccess ? 0 : -5;
+        static const std::vector<long long> zeros((size_t)STAMP_WGS * STAMP_SLOTS, 0);
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_stamps), zeros.data(), sizeof(long long) * zeros.size()) == hipSuccess ? 0 : -4;
     }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_stamp_rows), &filter_rows, sizeof(int)) != hipSuccess) return -1;
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spmv_stamps), sizeof(long long) * (size_t)count) != hipSuccess) return -2;
