@@ -377,7 +377,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int SIGMA = 2048;           // sorting window (rows)
 constexpr int SLONG = 96;             // more entries than this in one block: the row is summed by a wave of its own
-constexpr int SU = 4;                 // units of a slice in flight per batch
+constexpr int SU = 4;                 // units of a slice in flight per batch (8: same time -- the launch is not bound by round trips per slice)
 struct SellDims { int nrows, ncols, nsl, wpb; };   // nsl = slices per column block
 template <typename T> struct SellOf;
 template <> struct SellOf<double> { static constexpr int E = 2; using CV = unsigned; };

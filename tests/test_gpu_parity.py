@@ -359,12 +359,14 @@ SPARSE_CASES = [(ProblemClass.randomQp, 200, 0), (ProblemClass.isotonicRegressio
                 (ProblemClass.randomQp, 2000, 3000)]
 
 
-@pytest.mark.parametrize("blocked", ["0", "1"])      # CSR-stream SpMV (gathers through L1/L2) / column-blocked SpMV (x block in LDS)
+# CSR-stream SpMV (gathers through L1/L2) / column-blocked SpMV with the x block in LDS: sliced form (k_spmv_sell, the default) / task form (k_spmv_blk)
+@pytest.mark.parametrize("blocked", ["0", "1", "tasks"])
 @pytest.mark.parametrize("pc,n,m", SPARSE_CASES)
 def test_cg_path_iterates_match_oracle(gpu, c_oracle, monkeypatch, pc, n, m, blocked):
     """With the inner tolerance driven to 1e-13 both CG implementations solve the linear system to fp64 accuracy, so the
     ADMM iterates must agree tightly (the summation order inside the SpMVs differs)."""
-    monkeypatch.setenv("QPS_SPMV_BLOCKED", blocked)   # read when the handle is created
+    monkeypatch.setenv("QPS_SPMV_BLOCKED", "0" if blocked == "0" else "1")   # read when the handle is created
+    monkeypatch.setenv("QPS_SPMV_SELL", "0" if blocked == "tasks" else "1")
     P, q, A, l, u = GenerateRandomQP(pc, n, numConstraints=m, rng=make_rng(1234, 80 + int(pc)))
     with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
         for K in (25, 50):
@@ -377,13 +379,15 @@ def test_cg_path_iterates_match_oracle(gpu, c_oracle, monkeypatch, pc, n, m, blo
             assert rel(x, xo) <= 1e-7 and rel(z, io["z"]) <= 1e-7 and rel(y, io["y"]) <= 1e-6
 
 
-def test_cg_path_blocked_spmv_with_long_empty_and_ragged_rows(gpu, c_oracle, monkeypatch):
+@pytest.mark.parametrize("sell", ["1", "0"])           # sliced form (rows > 96 entries per block leave the slices) / task form (rows > 2048 leave the tasks)
+def test_cg_path_blocked_spmv_with_long_empty_and_ragged_rows(gpu, c_oracle, monkeypatch, sell):
     """The column-blocked SpMV on a matrix built to hit every branch of its layout: rows with more entries in one column block than a task holds
     (> 2048: a dense row across the wide block, dense columns of A = long rows of A'), rows of several hundred entries, a run of empty rows longer than
     a task may hold, a narrow last column block, a row count that is no multiple of anything -- against the oracle's matrix-free CG at iterate level,
     and the plugin pair against the host's products."""
     import scipy.sparse as sp
     monkeypatch.setenv("QPS_SPMV_BLOCKED", "1")
+    monkeypatch.setenv("QPS_SPMV_SELL", sell)
     rng = make_rng(91, 0)
     n, m = 8000, 5003                                      # fp64: column blocks of 7168 -> A has blocks of 7168 + 832 columns, A' one block
     A = sp.random(m, n, density=4e-3, random_state=np.random.RandomState(5), data_rvs=rng.standard_normal, format="lil")
@@ -417,12 +421,14 @@ def test_cg_path_blocked_spmv_with_long_empty_and_ragged_rows(gpu, c_oracle, mon
         assert abs(info["resDual"] - np.abs(Pc @ xk + q + At @ yk).max()) <= 1e-8 * max(1.0, info["resDual"])
 
 
+@pytest.mark.parametrize("sell", ["1", "0"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_cg_path_column_blocked_spmv_with_several_blocks(gpu, c_oracle, monkeypatch, dtype):
+def test_cg_path_column_blocked_spmv_with_several_blocks(gpu, c_oracle, monkeypatch, dtype, sell):
     """n = 9000, m = 16000: A has two column blocks, A' three (fp64: 7168 columns per block; one / two in fp32), so the partial sums per block,
     the fused sum-while-loading of A u inside the A' product and the one-launch combine are all exercised."""
     from quadraticprogramsolver_amd.generator import GenerateSparseBenchmarkQP
     monkeypatch.setenv("QPS_SPMV_BLOCKED", "1")       # (auto-selected from 200 k non-zeros per matrix; P has 169 k here)
+    monkeypatch.setenv("QPS_SPMV_SELL", sell)
     n, m = 9000, 16000
     P, q, A, l, u = GenerateSparseBenchmarkQP(n, m, densityA=2e-3, seed=99)
     with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg", dtype=dtype) as prob:
