@@ -30,6 +30,36 @@ def shard_range(total: int, rank: int, world_size: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def shard_assign(total: int, rank: int, world_size: int, assign: str = "contiguous", work=None):
+    """Indices of the independent QPs owned by `rank` ("balance by assigning QPs round-robin or by work-stealing").
+
+    ``contiguous``  the slabs of `shard_range` (QP b -> rank b // ceil(total / world)): what the fixed-K throughput line uses -- every QP runs the
+                    same number of iterations there, so equal counts are equal work, and a slab is one batched handle.
+    ``round_robin`` QP b -> rank b % world: for runs to a tolerance, where the iteration count differs from QP to QP (BASELINE config 4: 425-975
+                    iterations inside one slab) and neighbouring QPs of a generated set tend to resemble each other.
+    ``lpt``         longest-processing-time-first on a per-QP work estimate `work[b]` (e.g. the iteration counts of a previous solve of the same set,
+                    or of a loose-tolerance pre-solve): QPs by decreasing work, each to the rank with the least work so far; ties by index, so
+                    every rank computes the same assignment without talking to the others.
+    No data-path collective in any mode: a rank only needs to know its own list."""
+    if assign == "contiguous":
+        begin, end = shard_range(total, rank, world_size)
+        return list(range(begin, end))
+    if assign == "round_robin":
+        return list(range(rank, total, world_size))
+    if assign == "lpt":
+        if work is None or len(work) != total:
+            raise ValueError("assign='lpt' needs a work estimate per QP")
+        load = [0.0] * world_size
+        mine = []
+        for b in sorted(range(total), key=lambda i: (-float(work[i]), i)):
+            r = min(range(world_size), key=lambda k: (load[k], k))
+            load[r] += float(work[b])
+            if r == rank:
+                mine.append(b)
+        return sorted(mine)
+    raise ValueError(f"unknown assignment {assign!r}")
+
+
 def init_process_group(info: RankInfo, prefer: str | None = None):
     """Returns the backend actually in use ("nccl" == RCCL on ROCm, or "gloo"), or None for a single process.
 

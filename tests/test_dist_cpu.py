@@ -18,6 +18,35 @@ def test_shard_ranges_tile_the_batch():
     assert qd.shard_range(256, 3, 8) == (96, 128)     # BASELINE config 4: QP b -> GPU b // 32
 
 
+def test_balanced_assignments_cover_the_batch_and_even_out_the_work():
+    """Runs to a tolerance: the iteration count differs from QP to QP, so equal counts of QPs are not equal work.  Data: the per-QP iteration counts
+    of BASELINE config 4's 256 QPs run to eps = 1e-6 on one MI355X (tests/golden/c4_time_to_eps_iterations.json, written by
+    tests/tools/gpu_c4_iteration_counts.py: 400 .. 1425 iterations).  Every mode must hand out each QP exactly once; on the recorded counts the ranks'
+    summed iterations stay within 10 % of each other for round-robin and within 1 % for LPT -- where LPT is given the recorded counts themselves as its
+    work estimate, i.e. its best case.  (Measured spreads at 8 ranks: contiguous 9.8 %, round-robin 9.1 %, LPT 0.8 %: the counts of this set do not drift
+    with the index, so round-robin gains little over slabs; the gain is LPT's.)"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = json.load(open(os.path.join(root, "tests", "golden", "c4_time_to_eps_iterations.json")))
+    work = rec["iterations"]
+    assert len(work) == 256 and min(work) >= 25 and set(rec["flags"]) == {3}
+    for world in (2, 4, 8):
+        spread = {}
+        for assign in ("contiguous", "round_robin", "lpt"):
+            parts = [qd.shard_assign(256, r, world, assign=assign, work=work) for r in range(world)]
+            assert sorted(b for p in parts for b in p) == list(range(256)), (assign, world)
+            if assign == "contiguous":
+                assert parts == [list(range(*qd.shard_range(256, r, world))) for r in range(world)]
+            loads = [sum(work[b] for b in p) for p in parts]
+            spread[assign] = (max(loads) - min(loads)) / (sum(loads) / world)
+        assert spread["round_robin"] < 0.10 and spread["lpt"] < 0.01, (world, spread)
+        assert spread["lpt"] <= min(spread["contiguous"], spread["round_robin"]), (world, spread)
+    with pytest.raises(ValueError):
+        qd.shard_assign(8, 0, 2, assign="lpt")
+    with pytest.raises(ValueError):
+        qd.shard_assign(8, 0, 2, assign="nope")
+
+
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     info = qd.rank_info_from_env()
