@@ -54,7 +54,8 @@ typedef enum { QPS_F64 = 0, QPS_F32 = 1 } qps_dtype;
 
 /* which linear-system path replaces the reference plugin pair */
 typedef enum {
-    QPS_LINSYS_AUTO = 0,        /* dense handle -> QPS_LINSYS_CHOLESKY, CSC handle -> QPS_LINSYS_CG                */
+    QPS_LINSYS_AUTO = 0,        /* dense handle -> QPS_LINSYS_CHOLESKY; CSC handle -> the reference's modeAuto rule on the handle's
+                                   sizes (qps_linsys_auto: KKT_LDL or CG), CG when the direct factor does not fit the device plugin */
     QPS_LINSYS_CHOLESKY = 1,    /* reduced form P + sigma I + rho A'A, one Cholesky + two triangular sweeps / it   */
     QPS_LINSYS_CG = 2,          /* matrix-free CG on the reduced operator (LinearSystemSolvers.jl:145-186)         */
     QPS_LINSYS_KKT_LDL = 3      /* sparse L D L' of the quasi-definite KKT matrix [P + sigma I  A'; A  -I/rho], the reference's

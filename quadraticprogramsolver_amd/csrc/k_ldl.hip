@@ -51,9 +51,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_ldl_level_diag(int c0, int c1, const int* __restrict__ rp, const int* __restrict__ ci, const T* __restrict__ vr,
                                                         const T* __restrict__ D0, T* __restrict__ D, T* __restrict__ Dinv,
                                                         const signed char* __restrict__ sign, int* __restrict__ fail) {
-    const int g = (blockIdx.x * 256 + threadIdx.x) / GL, lane = threadIdx.x % GL;
-    const int j = c0 + g;
-    const bool valid = j < c1;
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GL; const int lane = threadIdx.x % GL;   // 64-bit: a level may hold more than 2^28 entries
+    const bool valid = (int64_t)c0 + g < (int64_t)c1;              // tested before narrowing
+    const int j = valid ? (int)(c0 + g) : c0;
     T s = T(0);
     if (valid)
         for (int k = rp[j] + lane; k < rp[j + 1]; k += GL) { const T l = vr[k]; s += l * l * D[ci[k]]; }
@@ -69,9 +69,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_ldl_level_offdiag(int q0, int q1, const int* __restrict__ rp, const int* __restrict__ ci, const int* __restrict__ ri,
                                                            const int* __restrict__ cj, const int* __restrict__ csc2csr, const T* __restrict__ D,
                                                            const T* __restrict__ Dinv, T* __restrict__ vr, T* __restrict__ vc) {
-    const int g = (blockIdx.x * 256 + threadIdx.x) / GL, lane = threadIdx.x % GL;
-    const int q = q0 + g;
-    const bool valid = q < q1;
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GL; const int lane = threadIdx.x % GL;   // 64-bit: a level may hold more than 2^28 entries
+    const bool valid = (int64_t)q0 + g < (int64_t)q1;              // tested before narrowing
+    const int q = valid ? (int)(q0 + g) : q0;
     T s = T(0); int p = 0, j = 0;
     if (valid) {
         const int i = ri[q]; j = cj[q]; p = csc2csr[q];
@@ -179,8 +179,8 @@ template <typename T, int LPR>
 __global__ __launch_bounds__(256) void k_ldl_bwd(int c0, int c1, int Ns, const int* __restrict__ cp, const int* __restrict__ ri, const T* __restrict__ vc,
                                                  const T* __restrict__ Dinv, T* __restrict__ b, const T* __restrict__ tx) {
     const int g = (blockIdx.x * 256 + threadIdx.x) / LPR, lane = threadIdx.x % LPR;
-    const int j = c0 + g;
-    const bool valid = j < c1;
+    const bool valid = (int64_t)c0 + g < (int64_t)c1;              // tested before narrowing
+    const int j = valid ? (int)(c0 + g) : c0;
     T s = T(0);
     if (valid) {
         T s0 = T(0), s1 = T(0);

@@ -700,7 +700,7 @@ template <typename T> struct SparseSolver : SolverBase {
     // sparse direct KKT plugin (LinearSystemSolvers.jl:16-107): built on first use from canonical host copies of the caller's CSC
     std::vector<int64_t> hPcp, hPri, hAcp, hAri; std::vector<double> hPnz, hAnz;
     std::unique_ptr<SparseLdl<T>> ldl; bool ldl_valid = false; double ldl_rho = 0, ldl_sigma = 0; int plugin_kind = QPS_LINSYS_CG;
-    int num_factorizations = 0;
+    int num_factorizations = 0; bool ldl_unfit = false;   // ldl_unfit: the analysis refused this pattern once (AUTO then goes to CG without asking again)
     // hipGraph replay of ONE plain iteration of the direct plugin (a dozen launches of 2-3 us of work each: the eager loop is bound by
     // the host's launch rate).  Keyed by the scalars baked into the kernel arguments; every pointer of the loop is fixed.
     struct IterGraph { double rho, sigma, alpha; hipGraphExec_t exec; };
@@ -955,6 +955,22 @@ template <typename T> struct SparseSolver : SolverBase {
             ocp[j + 1] = (int64_t)ori.size();
         }
     }
+    // Which plugin a request means on a CSC handle, with the direct one factorised.  QPS_LINSYS_AUTO is the reference's modeAuto rule
+    // (SolveQuadraticProgram.jl:143-151, qps_linsys_auto) on this handle's sizes and non-zero counts, so that a C caller passing AUTO reaches the direct
+    // KKT plugin exactly when the reference would; when the factor then does not fit the level-scheduled plugin (QPS_ERR_UNSUPPORTED from the analysis) an
+    // AUTO request falls back to CG -- an EXPLICIT QPS_LINSYS_KKT_LDL request still fails loudly.
+    int resolve_kind(int linsys, double rho, double sigma, bool force) {
+        int kind = linsys;
+        if (linsys == QPS_LINSYS_AUTO) kind = qps_linsys_auto(n, m, P.nnz, A.nnz, 1);
+        if (kind != QPS_LINSYS_KKT_LDL) return QPS_LINSYS_CG;
+        if (ldl_unfit && linsys == QPS_LINSYS_AUTO) return QPS_LINSYS_CG;
+        try { ldl_prepare(rho, sigma, force); }
+        catch (const QpsError& e) {
+            if (linsys == QPS_LINSYS_AUTO && e.code == QPS_ERR_UNSUPPORTED) { ldl_unfit = true; return QPS_LINSYS_CG; }
+            throw;
+        }
+        return QPS_LINSYS_KKT_LDL;
+    }
     // LaLdlInit / QDLdlInit / FacLdlInit (LinearSystemSolvers.jl:16-24, :47-55, :78-86): ordering + symbolic once per handle, numeric per (rho, sigma)
     void ldl_prepare(double rho, double sigma, bool force) {
         if (!ldl) {
@@ -1192,9 +1208,8 @@ template <typename T> struct SparseSolver : SolverBase {
         eps_pcg = p.epsPcg; itr_pcg = p.numItrPcg;
         const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;
         int convFlag = QPS_CONV_NUM_ITR;
-        plugin_kind = (p.linsys == QPS_LINSYS_KKT_LDL) ? QPS_LINSYS_KKT_LDL : QPS_LINSYS_CG;
         if (p.linsys == QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
-        if (plugin_kind == QPS_LINSYS_KKT_LDL) ldl_prepare(rho, sigma, !p.reuseFactor);             // SolveQuadraticProgram.jl:36 LinSysSolInit
+        plugin_kind = resolve_kind(p.linsys, rho, sigma, !p.reuseFactor);                           // SolveQuadraticProgram.jl:36 LinSysSolInit (incl. the factorisation)
         upload_vec(xh, x, n);
         const size_t nb_ = sizeof(T) * (size_t)(n + 64), mb_ = sizeof(T) * (size_t)(m + 64);
         HIPC(hipMemsetAsync(xp, 0, nb_, st)); HIPC(hipMemsetAsync(xx, 0, nb_, st));                 // LinOpCgInit: vXX = zeros (:147)
@@ -1290,8 +1305,8 @@ template <typename T> struct SparseSolver : SolverBase {
         HIPC(hipSetDevice(device));
         if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG && linsys != QPS_LINSYS_KKT_LDL)
             throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
-        plugin_kind = (linsys == QPS_LINSYS_KKT_LDL) ? QPS_LINSYS_KKT_LDL : QPS_LINSYS_CG;
-        if (plugin_kind == QPS_LINSYS_KKT_LDL) { ldl_prepare(rho, sigma, true); return; }            // LinearSystemSolvers.jl:18 / :49 / :81
+        plugin_kind = resolve_kind(linsys, rho, sigma, true);                                       // LinearSystemSolvers.jl:18 / :49 / :81
+        if (plugin_kind == QPS_LINSYS_KKT_LDL) return;
         HIPC(hipMemsetAsync(xx, 0, sizeof(T) * (size_t)(n + 64), st));                              // LinOpCgInit (:147)
         cg_total = 0; last_cg = 4;
     }
@@ -1401,7 +1416,9 @@ template <typename T> struct SparseProxQpSolver : ProxQpBase {
         try { sym = ldl_analyze((int)n, (int)me, kPcp.data(), kPri.data(), kAcp.data(), kAri.data(), 0, 8192, 64, 4096); }
         catch (const std::runtime_error& e) { throw QpsError(QPS_ERR_UNSUPPORTED, e.what()); }
         std::unique_ptr<SparseLdl<T>> kkt = make_sparse_ldl<T>(st, std::move(sym), kPnz.data(), (int64_t)kPnz.size(), kAnz.data(), (int64_t)kAnz.size());
-        kkt->factorize(1.0 / delta, 0.0);                                                          // [P A'; A -delta I]: P must be positive definite, as the reference requires
+        // [P + delta I, A'; A, -delta I]: quasi-definite for every positive SEMI-definite P, so a singular P with a non-singular KKT matrix -- which the
+        // reference's `mK \\ vR` (an LU, ProxQP.jl:103-106) accepts -- factorises too; the refinement below runs against the UNSHIFTED system
+        kkt->factorize(1.0 / delta, delta);
         HIPC(hipMemsetAsync(x, 0, sizeof(T) * (size_t)(n + 64), st));
         HIPC(hipMemsetAsync(dual, 0, sizeof(T) * (size_t)(mtot + 64), st));
         HIPC(hipMemsetAsync(de, 0, sizeof(T) * (size_t)(mtot + 64), st));
@@ -1418,6 +1435,28 @@ template <typename T> struct SparseProxQpSolver : ProxQpBase {
             kkt->solve_raw(r1, r2, dx, dnu);
             axpby(n, T(1), x, T(1), dx, x);
             axpby(me, T(1), dual, T(1), dnu, dual);
+        }
+        {   // did the refinement converge?  Residual of the unshifted system once more, on the host (one-off): a singular or hopelessly conditioned
+            // [P A'; A 0] must fail HERE, as the reference's backslash does, not hand the loop a garbage start
+            ss->spmv(ss->P, x, r1, T(-1), ss->q, T(-1), nullptr, T(0), nullptr);
+            if (me > 0) {
+                HIPC(hipMemcpyAsync(de, dual, sizeof(T) * (size_t)me, hipMemcpyDeviceToDevice, st));
+                ss->spmv(ss->At, de, r1, T(-1), r1, T(1), nullptr, T(0), nullptr);
+                ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                axpby(me, T(1), g, T(-1), v, r2);
+            }
+            std::vector<double> hr((size_t)n), hq((size_t)n), hr2((size_t)std::max<int64_t>(me, 1), 0.0), hb((size_t)std::max<int64_t>(me, 1), 0.0);
+            ss->download_vec(r1, hr.data(), n); ss->download_vec(ss->q, hq.data(), n);
+            if (me > 0) { ss->download_vec(r2, hr2.data(), me); ss->download_vec(g, hb.data(), me); }
+            auto amax = [](const std::vector<double>& a_) { double m_ = 0; for (double t : a_) { if (std::isnan(t)) return (double)INFINITY; m_ = std::fmax(m_, std::fabs(t)); } return m_; };
+            // against the right-hand side ONLY: a singular system answers the shifted solve with |x| ~ 1 / delta, and a scale that included |x| would
+            // normalise the residual it leaves behind away
+            const double scale = std::fmax(1.0, std::fmax(amax(hq), amax(hb)));
+            const double res = std::fmax(amax(hr), amax(hr2)) / scale, tol = sizeof(T) == 8 ? 1e-6 : 1e-2;
+            if (!(res <= tol)) {
+                char bmsg[256]; snprintf(bmsg, sizeof bmsg, "qps_proxqp_init_kkt: the iterative refinement of [P A'; A 0] [x; y] = [-q; b] did not converge (relative residual %.3g > %.1g): the KKT matrix is singular or too ill-conditioned", res, tol);
+                throw QpsError(QPS_ERR_FACTORIZATION, bmsg);
+            }
         }
         if (mtot > 0) {
             ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);                    // G x
@@ -1447,6 +1486,9 @@ template <typename T> struct SparseProxQpSolver : ProxQpBase {
                     ss->spmv(ss->At, de, X2, T(1), nullptr, T(0), nullptr, T(0), nullptr);          // A'y (:262)
                     ss->spmv(ss->At, di, X3, T(1), nullptr, T(0), nullptr, T(0), nullptr);          // C'z (:263)
                 }
+                // mA * vX, mC * vX of CheckConvergence! (:264-265) by the product itself: the `v` the row updates used came back with the un-refined,
+                // un-pivoted L D L' solve, whose error (rho clamped up to 1e5, fp32) would otherwise go straight into the reported primal residual
+                if (mtot > 0) ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);
                 HIPC(hipMemsetAsync(slots, 0, 16 * sizeof(unsigned long long), st));
                 hipLaunchKernelGGL((pqrows::k_pq_norms<T>), dim3(64), dim3(256), 0, st, (int)n, (int)me, mtot, v, g, slack, X1, X2, X3, ss->q, slots);
                 HIPC(hipMemcpyAsync(slots_host, slots, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));

@@ -170,6 +170,41 @@ def test_mode_auto_follows_the_reference_rule(gpu, c_oracle):
     assert gpu.AutoLinearSolverMode(Pd, Ad) == gpu.LinearSolverMode.modeItertaive
 
 
+def test_auto_at_the_c_abi_on_a_csc_handle(gpu, c_oracle, monkeypatch):
+    """A C consumer that leaves `qps_params.linsys` at QPS_LINSYS_AUTO on a CSC handle gets the reference's modeAuto rule (SolveQuadraticProgram.jl:143-151)
+    evaluated on the handle's own sizes: the direct KKT L D L' for a small sparse problem (no inner CG iterations, the direct oracle's iterates), CG beyond 5000
+    rows -- and CG too when the direct factor is refused by the analysis (forced here with QPS_LDL_MAX_LEVELS = 1), while an EXPLICIT request for the direct
+    plugin still fails with QPS_ERR_UNSUPPORTED."""
+    from quadraticprogramsolver_amd import _lib
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.lassoOptimization, 10, rng=make_rng(5, 1))          # 2040 rows, density < 0.001: direct
+    kw = dict(numIterations=20000, ϵAbs=1e-7, ϵRel=1e-7, ρ=0.1, adptΡ=True)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=20000, epsAbs=1e-7, epsRel=1e-7, rho=0.1, adptRho=True, linsys=c_oracle.KIND_KKT_LDL_SPARSE)
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:                                    # a CSC handle ...
+        prob.linsys = _lib.QPS_LINSYS_AUTO                                                            # ... driven with linsys = AUTO
+        x = np.zeros(P.shape[0]); info = {}
+        flag = prob.solve(x, info=info, **kw)
+        assert info["cgIterations"] == 0 and int(flag) == io["convFlag"] and info["iterations"] == io["iterations"]
+        assert np.abs(x - xo).max() <= ABS_DEV_THR
+    monkeypatch.setenv("QPS_LDL_MAX_LEVELS", "1")                                                     # the analysis now refuses every pattern
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
+        prob.linsys = _lib.QPS_LINSYS_AUTO
+        x = np.zeros(P.shape[0]); info = {}
+        flag = prob.solve(x, info=info, numIterations=20000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
+        assert info["cgIterations"] > 0 and int(flag) in (2, 3)                                       # fell back to CG, solved all the same
+        assert np.abs(x - xo).max() <= 1e-3 * max(1.0, np.abs(xo).max())
+        prob.linsys = _lib.QPS_LINSYS_KKT_LDL
+        with pytest.raises(_lib.QpsError) as ei:
+            prob.solve(np.zeros(P.shape[0]), **kw)
+        assert ei.value.status == 8                                                                   # QPS_ERR_UNSUPPORTED
+    monkeypatch.delenv("QPS_LDL_MAX_LEVELS")
+    P, q, A, l, u = GenerateRandomQP(ProblemClass.randomQp, 4000, numConstraints=2000, densityFctr=0.003, rng=make_rng(5, 2))   # 6000 rows: iterative
+    with gpu.QuadraticProgram(P, q, A, l, u, linsys="cg") as prob:
+        prob.linsys = _lib.QPS_LINSYS_AUTO
+        x = np.zeros(P.shape[0]); info = {}
+        flag = prob.solve(x, info=info, numIterations=4000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True)
+        assert info["cgIterations"] > 0 and int(flag) in (2, 3)
+
+
 def test_ldl_refuses_what_it_cannot_hold(gpu):
     """A dense handle has no sparse KKT plugin; the error is explicit (no silent fall back to another plugin)."""
     from quadraticprogramsolver_amd import _lib

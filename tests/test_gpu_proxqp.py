@@ -167,6 +167,50 @@ def test_sparse_iterates_and_report_match_oracle(gpu, po, n, me, mi, feasible, a
             assert abs(rg["DualResidual"] - rr["DualResidual"]) <= 1e-7 * max(1.0, rr["DualResidual"])
 
 
+def test_sparse_kkt_initialisation_with_singular_p_and_loud_failure(gpu):
+    """ProxQP.jl:95-115 solves [P A'; A 0] \\ [-q; b] with an LU: a positive SEMI-definite P is fine as long as the KKT matrix is non-singular (P positive
+    definite on the null space of A).  The device factorises [P + delta I, A'; A, -delta I] and refines against the unshifted system, so that case
+    initialises too -- checked against a host solve of the exact system -- while a genuinely singular KKT matrix (a zero direction of P inside the null
+    space of A) is reported as QPS_ERR_FACTORIZATION instead of handing the loop a garbage start."""
+    import scipy.sparse as sp
+    rng = make_rng(1517, 77)
+    n, me, mi = 200, 80, 150
+    dvals = np.concatenate([np.zeros(60), 0.5 + rng.random(n - 60)])           # P = diag: 60 zero directions
+    P = sp.diags(dvals).tocsc()
+    A = sp.hstack([sp.identity(me), sp.random(me, n - me, density=0.1, random_state=np.random.default_rng(3), data_rvs=rng.standard_normal)]).tocsc()
+    C = sp.random(mi, n, density=0.05, random_state=np.random.default_rng(4), data_rvs=rng.standard_normal, format="csc")
+    q = rng.standard_normal(n); b = rng.standard_normal(me); d = rng.standard_normal(mi)
+    K = np.block([[P.toarray(), A.toarray().T], [A.toarray(), np.zeros((me, me))]])          # A pins x_0..x_79, which covers the 60 zero directions
+    assert np.linalg.matrix_rank(K) == n + me
+    ref = np.linalg.solve(K, np.concatenate([-q, b]))
+    with gpu.ProxQP(P, q, A, b, C, d) as prob:
+        assert rel(prob.vX, ref[:n]) <= 1e-7 and rel(prob.vY, ref[n:]) <= 1e-6
+        assert np.abs(prob.vS - np.maximum(d - C @ prob.vX, 0.0)).max() <= 1e-9 * max(1.0, np.abs(prob.vS).max()) and np.all(prob.vZ == 0.0)
+    # now a zero direction of P that A does not touch: the KKT matrix is singular
+    A2 = sp.hstack([sp.csc_matrix((me, 1)), A[:, 1:]]).tocsc()                   # column 0 of A removed, P[0, 0] = 0
+    assert np.linalg.matrix_rank(np.block([[P.toarray(), A2.toarray().T], [A2.toarray(), np.zeros((me, me))]])) < n + me
+    with pytest.raises(gpu.QpsError) as e:
+        gpu.ProxQP(P, q, A2, b, C, d)
+    assert e.value.status == 4 and ("did not converge" in e.value.message or "pivot" in e.value.message)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 2e-3)])
+def test_sparse_reported_primal_residual_is_the_true_one_at_large_rho(gpu, dtype, tol):
+    """CheckConvergence! recomputes mA * vX and mC * vX (ProxQP.jl:264-265).  With rho at 1e5 the KKT system [P + sigma I, G'; G, -I/rho] is solved
+    without pivoting or refinement, so the G x that comes back with the solve carries its error; the reported primal residual must be the one of the
+    returned state all the same: max(|A x - b|, |C x + s - d|) recomputed on the host, and the sparse and the dense solver agree on it."""
+    P, q, A, b, C, d = make_sparse_problem(400, 100, 600, 53)
+    kw = dict(numIterations=100, numItrConv=50, ρ=1e5, σ=1e-2, adptΡ=False)
+    out = {}
+    for name, mats in (("sparse", (P, A, C)), ("dense", (P.toarray(), A.toarray(), C.toarray()))):
+        with gpu.ProxQP(mats[0], q, mats[1], b, mats[2], d, dtype=dtype) as prob:
+            rep = gpu.SolveQuadraticProgramProxQP(prob, **kw)
+            true_res = max(np.abs(A @ prob.vX - b).max(), np.abs(C @ prob.vX + prob.vS - d).max())
+            out[name] = (rep["PrimalResidual"], true_res)
+            assert abs(rep["PrimalResidual"] - true_res) <= tol * max(1.0, true_res) + (1e-12 if dtype == "f64" else 1e-5), (name, rep["PrimalResidual"], true_res)
+    assert abs(out["sparse"][0] - out["dense"][0]) <= 10 * tol * max(1.0, out["dense"][0]) + (1e-10 if dtype == "f64" else 1e-4)
+
+
 def test_sparse_proxqp_fp32_and_demo_defaults(gpu, po):
     """fp32 sparse handle tracks the fp64 restatement to 1e-3; the reference's default keywords (ProxQP.jl:118) converge on a sparse problem."""
     P, q, A, b, C, d = make_sparse_problem(400, 100, 600, 51)
