@@ -706,10 +706,64 @@ static int chol_step_width() {
     static const int w = [] { const char* e = getenv("QPS_CHOL_STEP"); return (e && atoi(e) == 64) ? 64 : 128; }();
     return w;
 }
+// Depth-1 look-ahead for the 128-column steps (QPS_CHOL_LOOKAHEAD=1; round-3 review item 4).  Step k + 1 reads only the first 128 columns of what the
+// trailing update of step k writes, so that update is cut in two: the 128 columns the next step needs (main stream) and the rest, which runs on a second
+// stream beside the next step launch -- a launch of at most 62 workgroups, each a chain of single-CU latencies, that leaves three quarters of the chip idle.
+// One event each way per step.  The side stream and its events are per host thread and device (handles of a device driven from several threads do not share them).
+namespace {
+struct LookaheadLane { hipStream_t side = nullptr; hipEvent_t stepped = nullptr, rest_done = nullptr; };
+struct LookaheadPool {
+    LookaheadLane lane[kMaxDevices];
+    ~LookaheadPool() { for (auto& l : lane) { if (l.stepped) (void)hipEventDestroy(l.stepped); if (l.rest_done) (void)hipEventDestroy(l.rest_done); if (l.side) (void)hipStreamDestroy(l.side); } }
+    LookaheadLane* get(int dev) {
+        if (dev < 0 || dev >= kMaxDevices) return nullptr;
+        LookaheadLane& l = lane[dev];
+        if (!l.side) {
+            if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.stepped, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&l.rest_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        return &l;
+    }
+};
+thread_local LookaheadPool g_lookahead;
+bool chol_lookahead() { static const bool on = [] { const char* e = getenv("QPS_CHOL_LOOKAHEAD"); return e && atoi(e) != 0; }(); return on; }
+}  // namespace
+
 template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch, T* scratch) {
     (void)hipMemsetAsync(fail_dev, 0, sizeof(int) * batch, st);
     const int nblk = NP / 64;
     const int64_t sM = (int64_t)NP * NP, sD = (int64_t)nblk * 4096;
+    if (scratch && chol_step_width() == 128 && chol_lookahead() && batch == 1 && nblk >= 8) {
+        LookaheadLane* la = g_lookahead.get(current_device());
+        if (la) {
+            const int64_t sS = chol_scratch_elems(NP);
+            bool rest_pending = false;
+            for (int cb = 0; cb < nblk; cb += 2) {
+                const int w = (nblk - cb >= 2) ? 2 : 1;
+                const int rem = NP - (cb + w) * 64;
+                hipLaunchKernelGGL((k_chol_step<T>), dim3(rem > 0 ? rem / 64 : 1, batch), dim3(256), 0, st, M, (int64_t)NP, cb, w, rem / 64, dinv, scratch,
+                                   fail_dev, sM, sD, sS);
+                if (rem <= 0) break;
+                const T* A21 = M + (int64_t)(cb + w) * 64 * NP + cb * 64;
+                T* A22 = M + (int64_t)(cb + w) * 64 * NP + (cb + w) * 64;
+                const int head = std::min(128, rem), tail = rem - head;
+                if (tail > 0) (void)hipEventRecord(la->stepped, st);                      // the panel L21 of this step is complete
+                if (rest_pending) { (void)hipStreamWaitEvent(st, la->rest_done, 0); rest_pending = false; }   // the previous rest also wrote these 128 columns
+                // the 128 columns the next step reads: rows [0, rem) x columns [0, head), lower tiles
+                gemm<T>(st, rem, head, w * 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true, 1, 0, 0, 0, 0);
+                if (tail > 0) {   // the rest, beside the next step launch
+                    (void)hipStreamWaitEvent(la->side, la->stepped, 0);
+                    const T* A21t = A21 + (int64_t)head * NP;
+                    gemm<T>(la->side, tail, tail, w * 64, T(-1), A21t, NP, true, A21t, NP, true, T(1), A22 + (int64_t)head * NP + head, NP, true, 1, 0, 0, 0, 0);
+                    (void)hipEventRecord(la->rest_done, la->side);
+                    rest_pending = true;
+                }
+            }
+            if (rest_pending) (void)hipStreamWaitEvent(st, la->rest_done, 0);
+            hipLaunchKernelGGL((k_chol_unstash<T>), dim3((nblk + 1) / 2, 3, batch), dim3(256), 0, st, M, (int64_t)NP, scratch, nblk, sM, sS);
+            return;
+        }
+    }
     if (scratch && chol_step_width() == 128) {
         const int64_t sS = chol_scratch_elems(NP);
         for (int cb = 0; cb < nblk; cb += 2) {
