@@ -375,7 +375,8 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
 // (Tried and dropped: slices handed out one ticket at a time from a per-block atomic counter, to even out the workgroups' lifetimes -- ~600 waves
 // adding to one address serialise at ~80 ns each: 240 us per product instead of 27.  Non-temporal loads of the matrix: no difference.)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int SIGMA = 2048;           // sorting window (rows)
+constexpr int SIGMA = 2048;           // sorting window (rows).  8192 measured: slice padding on BASELINE config 3 5.2 % -> 1.4 % of the entries (pair rounding: 7 % either
+                                      // way), products 27.9 / 17.1 -> 33.4 / 18.9 us -- the row sums of a slice then scatter over 64 KB of the partial sums instead of 16 KB
 constexpr int SLONG = 96;             // more entries than this in one block: the row is summed by a wave of its own
 constexpr int SU = 4;                 // units of a slice in flight per batch (8: same time -- the launch is not bound by round trips per slice)
 struct SellDims { int nrows, ncols, nsl, wpb; };   // nsl = slices per column block
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_sell(SellDims a, const int* _
                 }
             }
         }
-        if (pm != 0xffffu) pout[(s >> 5) * SIGMA + (int)pm] = acc;              // 32 slices per sorting window
+        if (pm != 0xffffu) pout[(s / (SIGMA / 64)) * SIGMA + (int)pm] = acc;    // SIGMA / 64 slices per sorting window
         QPS_STAMP(3 + (s - s_begin) / NW);
     }
     // long rows of this block: one wave per row
