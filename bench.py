@@ -273,7 +273,7 @@ def run_dense(args, cfg, info, device, qps, qd, np, sync, problem=None):
         out["setup_ms"] = round(setup_info.get("tSetup", 0.0) * 1e3, 2)
         if refactors:
             out["refactor"] = {"count": refactors, "ms_each": round(t_refactor / refactors * 1e3, 3), "share_of_loop_time": round(t_refactor / elapsed, 3)}
-        out["kernels"] = kernel_list(ktimes, args.config)
+        out["kernels"] = kernel_list(ktimes, args.config + (f"_trsv{args.trsv_block}" if args.trsv_block else ""))
         sw = next((k for k in ktimes if k["name"].startswith("sweeps(fused")), None)
         if sw:   # the fused kernel reads the triangle once; SURVEY §8d's figure for the two sweeps it replaces is s*(n(n+1) + 4n)
             dur = sw["seconds"] / sw["launches"]

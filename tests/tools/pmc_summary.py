@@ -1,15 +1,25 @@
 """Per-kernel HBM traffic from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units).
 gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced
-streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores."""
-import csv, sys, re, json, collections
+streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+Usage: pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv [out.json] [command that was profiled]
+The summary carries `_meta`: the git HEAD and the digest of the kernel sources it was measured on (bench.py reports a traffic figure only
+when that digest is the running build's)."""
+import collections, csv, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from bench import build_head, csrc_digest
+
+
 def load(path):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         mm = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"]); name = mm.group(1) if mm else r["Kernel_Name"]
         d[name].append(float(r["Counter_Value"]))
     return d
+
+
 f, w = load(sys.argv[1]), load(sys.argv[2])
-out = {}
+out = {"_meta": {"head": build_head(), "csrc_sha16": csrc_digest(), "command": sys.argv[4] if len(sys.argv) > 4 else None,
+                 "method": "two separate rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, --kernel-trace only); hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE"}}
 for k in sorted(f, key=lambda k: -sum(f[k])):
     if not k.startswith("k_"): continue
     fetch_kib = sum(f[k]) / len(f[k]); write_kib = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)
