@@ -174,7 +174,7 @@ def roofline_of(kernel_label, seconds, launches, algo_bytes_per_launch, traffic,
 # rocprofv3 kernel names of the profiler categories (for the side-by-side averages in `kernels[]`)
 ROCPROF_NAME = [(r"^apass\(fused A-pass", r"k_apass<.*false, 0>"), (r"^apass\(check variant", r"k_apass<.*true, 0>"),
                 (r"^sweeps\(fused", r"k_sweep_fused(_wave)?<"), (r"^colsum\(", r"k_colsum<"), (r"^trsv_forward", r"k_trsv_blocked<.*false, \d+>"),
-                (r"^trsv_backward", r"k_trsv_blocked<.*true, \d+>"), (r"^spmv_blk\(", r"k_spmv_blk<"), (r"^admm_small", r"k_admm_small")]
+                (r"^trsv_backward", r"k_trsv_blocked<.*true, \d+>"), (r"^spmv_blk\(", r"k_spmv_(sell|blk)<"), (r"^admm_small", r"k_admm_small")]
 
 
 def rocprof_stats(config):
@@ -413,8 +413,8 @@ def run_sparse(args, cfg, info, device, qps, qd, np, sync):
         if blk:   # both column-blocked products of a CG iteration run the same kernel: they are timed in pairs and reported together
             secs, launches = sum(k["seconds"] for k in blk), sum(k["launches"] for k in blk)
             bytes_avg = sum(k["algo_bytes"] * k["launches"] for k in blk) / launches
-            traffic, src = pmc_traffic("c3", r"k_spmv_blk<")
-            out["roofline"] = roofline_of("k_spmv_blk ([P;A] u and A' v of a CG iteration, x block in LDS)", secs, launches, bytes_avg, traffic, src,
+            traffic, src = pmc_traffic("c3", r"k_spmv_(sell|blk)<")
+            out["roofline"] = roofline_of("column-blocked SpMV k_spmv_sell ([P;A] u and A' v of a CG iteration, x block in LDS; QPS_SPMV_SELL=0: k_spmv_blk)", secs, launches, bytes_avg, traffic, src,
                                           {"note": "the ~155 MB working set is Infinity-Cache resident (256 MiB): fractions are against the HBM peak all the same"})
         else:
             out["roofline"] = None
