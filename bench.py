@@ -210,7 +210,19 @@ def kernel_list(ktimes, config=None, iters_per_s=None):
             if hit:
                 name, (avg, calls) = max(hit, key=lambda t: t[1][1])
                 e["rocprof_avg_us"] = round(avg, 2)
+                e["_rocprof_kernel"] = name
         out.append(e)
+    # several categories served by ONE kernel name (the two products of a CG iteration): rocprofv3 cannot tell them apart, its figure is their joint average
+    seen = {}
+    for e in out:
+        if e.get("_rocprof_kernel"):
+            seen.setdefault(e["_rocprof_kernel"], []).append(e)
+    for name, es in seen.items():
+        if len(es) > 1:
+            for e in es:
+                e["rocprof_note"] = f"joint average over {len(es)} categories that run the same kernel ({name.split('(')[0][:40]})"
+    for e in out:
+        e.pop("_rocprof_kernel", None)
     if src:
         out.append({"name": "_rocprof_source", "file": f"profiles/{src}"})
     return out
