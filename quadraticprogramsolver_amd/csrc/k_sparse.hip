@@ -143,7 +143,7 @@ __device__ int g_spmv_stamp_rows = 0;
 #define QPS_STAMP(k) do { } while (0)
 #endif
 
-constexpr int BROWS = 1024;           // rows per task at most (their row pointers are staged in LDS)
+// (rows per task: at most 4 passes x (BTHREADS / LPR) rows = 512 or 256 -- the builder's `max_rows`; their row pointers are staged in LDS)
 constexpr int BMAXT = 64;             // tasks per workgroup at most (their descriptors are staged in LDS)
 // Optional fusion of the CG direction update into the x-block load of the operator's first product:  u_new = r + beta u_old,
 // beta from the ||r||^2 partials of the previous iteration; block (0,0) publishes the scalars (what k_cg_next_u does).
