@@ -262,6 +262,29 @@ def test_c2_full_size_iterates_against_the_oracle(gpu, c_oracle, c2_problem):
                     assert info["trsvBlock"] == 1024 and info["sweepVariant"] == 5, info
 
 
+def test_c2_full_size_time_to_eps_against_the_oracle(gpu, c_oracle):
+    """The other half of BASELINE.json's metric, time-to-eps, at full size beside the ORACLE (round-3 review item 1): dense n = 4096, m = 8192 fp64,
+    feasible variant (what bench.py's `time_to_eps` leg solves), eps = 1e-6 (SolveQuadraticProgram.jl:15 defaults), rho0 = 0.1, adaptive rho
+    (RunTests.jl:53-54).  The HIP path and c_oracle.solve must stop at the same check with the same flag after the same number of
+    re-factorisations, the solutions within RunTests.jl:93's 1e-5 -- through the default sweep and through the blocked back-substitution kernel."""
+    n, m = 4096, 8192
+    P, q, A, l, u = GenerateDenseBenchmarkQP(n, m, seed=1234, feasible=True)
+    xo, io = c_oracle.solve(P, q, A, l, u, numIterations=50000, epsAbs=1e-6, epsRel=1e-6, rho=0.1, adptRho=True)
+    assert io["convFlag"] == 3
+    with gpu.QuadraticProgram(P, q, A, l, u) as prob:
+        for nb in (0, 1024):
+            x = np.zeros(n); info = {}
+            flag = prob.solve(x, numIterations=50000, ϵAbs=1e-6, ϵRel=1e-6, ρ=0.1, adptΡ=True, trsvBlock=nb, info=info)
+            dev = np.abs(x - xo).max()
+            note(f"(b') C2 time-to-eps 1e-6 (feasible variant) trsvBlock={info['trsvBlock']}: flag {int(flag)}/{io['convFlag']} iterations {info['iterations']}/{io['iterations']} "
+                 f"refactors {info['numRefactor']}/{io['numRefactor']} rho {info['rhoFinal']:.12g}/{io['rhoFinal']:.12g} max|x-x_oracle| {dev:.3e}; "
+                 f"GPU {1e3 * info['tSetup']:.1f} + {1e3 * info['tLoop']:.1f} ms, CPU oracle {1e3 * io['tSetup']:.0f} + {1e3 * io['tLoop']:.0f} ms")
+            assert int(flag) == io["convFlag"] and info["iterations"] == io["iterations"] and info["numRefactor"] == io["numRefactor"]
+            assert abs(info["rhoFinal"] - io["rhoFinal"]) <= 1e-9 * io["rhoFinal"]
+            assert dev <= ABS_DEV_THR                                            # RunTests.jl:93
+            assert abs(info["resPrim"] - io["resPrim"]) <= 1e-6 * max(1.0, io["resPrim"]) and abs(info["resDual"] - io["resDual"]) <= 1e-6 * max(1.0, io["resDual"])
+
+
 def test_c3_full_size_iterates_against_the_oracle(gpu, c_oracle, c3_problem):
     """BASELINE configs[2] (sparse n = 50 000, m = 100 000): K = 5 iterations with the inner CG driven to epsPcg = 1e-12 (so that the inexact solve
     does not separate the two), HIP matrix-free CG plugin (column-blocked SpMV) vs the oracle's KIND_CG_MATFREE (LinearSystemSolvers.jl:145-186) on the
