@@ -5,6 +5,7 @@
 #include "qps_kernels.h"
 #include "wave_reduce.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace qps {
 
@@ -12,6 +13,10 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Vec16;                    // 16 bytes of T as a native vector
+template <> struct Vec16<double> { using type = d2; };
+template <> struct Vec16<float> { using type = f4; };
 
 template <typename T> struct Mfma;
 template <> struct Mfma<double> {
@@ -367,6 +372,16 @@ template <typename T> struct Acc64 {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) f(tile_of(wm, a) * 16 + Mfma<T>::row(lane, r), tile_of(wn, b) * 16 + (lane & 15), v[a][b][r]);
     }
+    // f(row, col, entry &): fill / modify the entries in place (vector element references cannot be bound: through a scalar)
+    template <typename F> __device__ __forceinline__ void foreach_ref(F&& f) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { T e = v[a][b][r]; f(tile_of(wm, a) * 16 + Mfma<T>::row(lane, r), tile_of(wn, b) * 16 + (lane & 15), e); v[a][b][r] = e; }
+    }
 };
 // c += A * B, all 64 x 64, operands in LDS.  TRI 1: B(k, j) = 0 for k > j (the transpose of a lower-triangular tile): the depth of a
 // column tile stops at its last column
@@ -547,6 +562,225 @@ __global__ __launch_bounds__(256) void k_chol_step(T* __restrict__ M, int64_t ld
         CHOL_T(8);
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// 128-column steps with the diagonal block OFF the chain of dependent launches (round 4).  In the chain above every step launch spends
+// ~25 us (fp32) / ~45 us (fp64) factorising and inverting its 128 x 128 diagonal block before any panel row is touched, and the trailing
+// update waits behind it.  Here the diagonal block of step k + 1 is factorised INSIDE the trailing-update launch of step k: workgroup
+// (0, 0) of that launch -- the first one dispatched -- forms the leading tile of the updated A22 itself (one round trip for its operands),
+// factorises and inverts it, takes the tiles (1, 0) and (1, 1) from the two workgroups that own them in the trailing GEMM (a counter in
+// global memory tells it they are stored; by then it has been busy for ~10 us, they need ~5) and finishes the 128 x 128 block while the
+// other workgroups run the trailing GEMM.  It leaves L00 / L10 / L11 (stash) and W00 / W11 (dinv) behind; the step launch (k_chol_panel)
+// then only loads those and forms its panel rows -- three 64^3 products.
+// LDS of the fused launch: the GEMM staging buffers + ONE tile.  The diagonal workgroup reuses the staging buffers as its second tile, as
+// the published panel of potrf_tile and as the scratch of tri_inv64, so the trailing GEMM keeps (almost) the occupancy of the plain k_gemm.
+// Forward progress: nobody waits for the diagonal workgroup inside the launch, and the two workgroups it waits for wait for nobody, so the
+// wait ends as soon as they have been dispatched and run; it is bounded all the same (a fixed number of polls, then the failure word is set
+// and the factorisation reports a breakdown instead of hanging).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: the bodies index register arrays
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// t00 = -(C - R0 R0') for the first 64 rows R0 of the panel A21 (64 x K, k contiguous), C = the leading tile of A22.  K = 0: -C.
+// The operand -- 64 rows x 128 columns of the panel, L2 hits -- is requested in ONE go with 16-byte loads and then fed through LDS 32 columns
+// at a time (row-major, row stride 4 x odd words: the MFMA fragment reads are conflict free): one memory round trip for the whole product.
+// (A staged loop with one slab of prefetch paid a round trip per 16 columns: 8 us, more beside the trailing GEMM.)
+template <typename T>
+__device__ __forceinline__ void diag_tile00(int K, const T* __restrict__ A21, const T* __restrict__ A22, int64_t ld, T* __restrict__ buf, Acc64<T>& t00) {
+    using V = typename Vec16<T>::type;             // (a native vector: arrays of HIP's float4 / double2 structs are not promoted to registers)
+    constexpr int VN = 16 / sizeof(T), KQ = 32, S = KQ + (sizeof(T) == 4 ? 4 : 2), VPT = 8 / VN, NQ = 4, VPR = KQ / VN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    t00.foreach_ref([&](int r, int c, T& v) { v = -A22[(int64_t)r * ld + c]; });   // the C tile first (older than every operand load)
+    if (K <= 0) return;                                                            // (K is 0 or NQ * KQ = 128: the fused chain has no other depth)
+    V x0[NQ * VPT];
+    static_for<0, NQ>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        static_for<0, VPT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int f = tid + 256 * j, i = f / VPR, kv = f % VPR;
+            x0[p * VPT + j] = *reinterpret_cast<const V*>(A21 + (int64_t)i * ld + p * KQ + kv * VN);
+        });
+    });
+    T* Aq = buf;
+    const int cl = lane & 15, kq = lane >> 4;
+    const int r0 = (wm * 16 + cl) * S, r1 = ((3 - wm) * 16 + cl) * S, c0 = (wn * 16 + cl) * S, c1 = ((3 - wn) * 16 + cl) * S;   // Acc64's tile interleaving
+    static_for<0, NQ>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if (p) __syncthreads();                                                    // the previous quarter is done being read
+        static_for<0, VPT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int f = tid + 256 * j, i = f / VPR, kv = f % VPR;
+            *reinterpret_cast<V*>(Aq + i * S + kv * VN) = x0[p * VPT + j];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KQ; kk += 4) {
+            const int kr = kk + kq;
+            const T a0 = Aq[r0 + kr], a1 = Aq[r1 + kr], b0 = Aq[c0 + kr], b1 = Aq[c1 + kr];
+            t00.v[0][0] = Mfma<T>::run(a0, b0, t00.v[0][0]); t00.v[0][1] = Mfma<T>::run(a0, b1, t00.v[0][1]);
+            t00.v[1][0] = Mfma<T>::run(a1, b0, t00.v[1][0]); t00.v[1][1] = Mfma<T>::run(a1, b1, t00.v[1][1]);
+        }
+    });
+}
+
+constexpr int DIAG_POLLS = 1 << 22;   // polls of the hand-off counter before the diagonal workgroup gives up (~1 s: never reached by a live launch)
+
+// Factor + inverse of the 128 x 128 (two) or 64 x 64 diagonal block: L00, L10, L11 -> stash (3 tiles), W00 = inv(L00), W11 = inv(L11) ->
+// dinv[cb], dinv[cb + 1].  t00: the NEGATED leading tile (diag_tile00); the tiles (1, 0) and (1, 1) are read from d10 / d11 (row stride ld) once
+// *ready == 2 (ready == nullptr: they are in place already).  tile0: one LDS tile; spare: 64 * TS elements of LDS that nobody else uses any
+// more (second tile / published potrf panel / tri_inv64 scratch in turn).
+template <typename T>
+__device__ __forceinline__ void diag_factor(Acc64<T>& t00, const T* __restrict__ d10, const T* __restrict__ d11, int64_t ld, int* ready, bool two, int cb,
+                                            T (*tile0)[TS<T>::v], T* spare, T* __restrict__ dinv, T* __restrict__ stash, int* fail) {
+    T (*B1)[TS<T>::v] = reinterpret_cast<T (*)[TS<T>::v]>(spare);
+    T (*Lp)[LPS] = reinterpret_cast<T (*)[LPS]>(spare);
+    const int pc = threadIdx.x & 63, pg = threadIdx.x >> 6;                        // tile_load's element order
+    __syncthreads();                                                               // the staging buffers (spare) are done being read
+    t00.foreach([&](int r, int c, T v) { tile0[r][c] = -v; });
+    __syncthreads();
+    CHOL_T(1);
+    potrf_tile<T>(tile0, Lp, cb * 64, fail);
+    CHOL_T(2);
+    tile_store<T>(stash, 64, tile0);                                               // L00
+    if (two && ready) {
+        // tiles (1, 0) and (1, 1) stored by their owners?  One lane polls (acquire at agent scope: this CU's L1 is invalidated, so the loads
+        // below, issued behind the barrier, see the owners' stores), then the counter is cleared for the next launch on this matrix.
+        if (threadIdx.x == 0) {
+            int polls = 0;
+            while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < 2 && ++polls < DIAG_POLLS) __builtin_amdgcn_s_sleep(2);
+            if (polls >= DIAG_POLLS && fail) atomicCAS(fail, 0, -1);               // never seen: reported as a breakdown (the data read below is then stale)
+            __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();                                                               // (also: the inverse below overwrites tile0 in place)
+    CHOL_T(3);
+    T pre[16];
+    if (two) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pre[i] = d10[(int64_t)(pg + 4 * i) * ld + pc];    // D10, in flight during the inverse
+    }
+    tri_inv64<T>(tile0, B1);                                                       // tile0 = W00 (the published panel in `spare` is dead)
+    CHOL_T(4);
+    tile_store<T>(dinv + (int64_t)cb * 4096, 64, tile0);
+    if (!two) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) B1[pg + 4 * i][pc] = pre[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pre[i] = d11[(int64_t)(pg + 4 * i) * ld + pc];        // D11, in flight during the product
+    __syncthreads();
+    Acc64<T> c;
+    c.zero(); mm64<T, 1>(c, lv(B1), lvT(tile0));                                   // L10 = D10 W00'
+    __syncthreads();
+    c.foreach([&](int r, int cc, T v) { B1[r][cc] = v; });
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile0[pg + 4 * i][pc] = pre[i];                   // D11 (W00 is not needed any more)
+    __syncthreads();
+    CHOL_T(5);
+    tile_store<T>(stash + 4096, 64, B1);                                           // L10
+    c.zero(); mm64<T>(c, lv(B1), lvT(B1));                                         // D11 -= L10 L10'
+    c.foreach([&](int r, int cc, T v) { tile0[r][cc] -= v; });
+    __syncthreads();                                                               // also: every read of B1 is done before potrf_tile publishes into it
+    CHOL_T(6);
+    potrf_tile<T>(tile0, Lp, cb * 64 + 64, fail);
+    CHOL_T(7);
+    tile_store<T>(stash + 8192, 64, tile0);                                        // L11
+    __syncthreads();
+    tri_inv64<T>(tile0, B1);                                                       // tile0 = W11
+    CHOL_T(8);
+    tile_store<T>(dinv + (int64_t)(cb + 1) * 4096, 64, tile0);
+    CHOL_T(9);
+}
+
+// Trailing update of the step that ended at block column cbn (A22 -= L21 L21', lower tiles, depth K = 128) + diagonal block of the NEXT
+// step (block columns cbn, cbn + 1) by workgroup 0.  K = 0 with a grid of one: the first diagonal block alone (it also clears the hand-off
+// counter of its matrix).  grid (ids, batch): id 0 = the diagonal workgroup, the ids behind it take the lower tiles of the g x g tile grid
+// (g = rows below the finished columns / 64) in the order (1, 0), (1, 1), (2, 0), ...  -- the two tiles the diagonal workgroup waits for first.
+// avoid = 1: ids that are multiples of 8 take no tile.  Workgroups are dealt round-robin over the 8 XCDs (observed placement, used for speed only), so
+// these are the ones that would share the diagonal workgroup's XCD: a trailing GEMM next to it (2 of its workgroups on the same CU, its traffic in the same
+// L2) doubles the time of the factorisation chain (potrf 7.8 -> 15.5 us fp32, 14.8 -> 31 us fp64; profiles/r04_b_chol_fused_microbench.log), which costs
+// the launch more than the eighth of the chip the GEMM gives up.
+// ready: one int per matrix (behind the stash tiles of the matrix).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_chol_update_diag(T* __restrict__ M, int64_t ld, int cbn, int K, int nblk, int g, int avoid, T* __restrict__ dinv,
+                                                             T* __restrict__ stash, int64_t ready_off, int* __restrict__ fail, int64_t sM, int64_t sD, int64_t sS) {
+    const int L = blockIdx.x;
+    const bool two = nblk - cbn >= 2;                                              // the next step is two blocks wide (workgroup-uniform)
+    M += (int64_t)blockIdx.y * sM;
+    __shared__ __attribute__((aligned(16))) T stage[2][2][GK][GLD];
+    __shared__ T tile0[64][TS<T>::v];
+    static_assert(2 * 2 * GK * GLD >= 64 * TS<T>::v && 2 * 2 * GK * GLD >= 64 * LPS && 2 * 2 * GK * GLD >= 64 * 36, "the staging buffers double as a tile");
+    const T* A21 = M + (int64_t)cbn * 64 * ld + (int64_t)cbn * 64 - K;             // rows of the finished panel below it: columns [64 cbn - K, 64 cbn)
+    T* A22 = M + (int64_t)cbn * 64 * ld + (int64_t)cbn * 64;
+    T* smat = stash + (int64_t)blockIdx.y * sS;
+    int* ready = reinterpret_cast<int*>(smat + ready_off);
+    if (L == 0) {                                                                  // the diagonal workgroup
+#if defined(QPS_DIAG_DEBUG) && QPS_DIAG_DEBUG == 1
+        if (K > 0) return;                                                         // (micro-benchmark only: the trailing GEMM of the fused launch alone)
+#endif
+        if (K == 0 && threadIdx.x == 0) __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CHOL_T(0);
+        Acc64<T> t00;
+        diag_tile00<T>(K, A21, A22, ld, &stage[0][0][0][0], t00);
+        diag_factor<T>(t00, A22 + 64 * ld, A22 + 64 * ld + 64, ld, K > 0 ? ready : nullptr, two, cbn, tile0, &stage[0][0][0][0], dinv + (int64_t)blockIdx.y * sD,
+                       smat + (int64_t)(cbn >> 1) * 3 * 4096, fail + blockIdx.y);
+        return;
+    }
+    if (avoid && (L & 7) == 0) return;
+    const int t = (avoid ? L - (L >> 3) : L);                                      // 1-based index into the lower tiles behind (0, 0)
+    if (t >= g * (g + 1) / 2) return;
+    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);                    // t = bi (bi + 1) / 2 + bj, 0 <= bj <= bi
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    gemm_tile<T, true, true>(K, T(-1), A21, ld, A21, ld, T(1), A22, ld, 0, bi, bj, stage[0], stage[1], nullptr);
+    if (bi == 1) {                                                                 // tiles (1, 0) and (1, 1): the diagonal workgroup is waiting for them
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Panel rows of the step at block columns cb, cb + 1 (both present), diagonal block already factorised by k_chol_update_diag:
+// X0 = A0 W00', X1 = (A1 - X0 L10') W11' for this workgroup's 64 rows.  grid (nrb, batch).
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_panel(T* __restrict__ M, int64_t ld, int cb, const T* __restrict__ dinv, const T* __restrict__ stash,
+                                                    int64_t sM, int64_t sD, int64_t sS) {
+    __shared__ T B0[64][TS<T>::v];
+    __shared__ T B1[64][TS<T>::v];
+    __shared__ T B2[64][TS<T>::v];
+    __shared__ T B3[64][TS<T>::v];
+    M += (int64_t)blockIdx.y * sM; dinv += (int64_t)blockIdx.y * sD; stash += (int64_t)blockIdx.y * sS + (int64_t)(cb >> 1) * 3 * 4096;
+    const int c0 = cb * 64;
+    T* Ab = M + (int64_t)(c0 + 128 + blockIdx.x * 64) * ld + c0;
+    tile_load<T>(B3, Ab, ld);                                                      // A0
+    tile_load<T>(B0, dinv + (int64_t)cb * 4096, 64);                               // W00
+    tile_load<T>(B1, stash + 4096, 64);                                            // L10
+    tile_load<T>(B2, dinv + (int64_t)(cb + 1) * 4096, 64);                         // W11
+    T a1[16];                                                                      // A1 in flight behind them (tile_load's element order)
+    {
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a1[i] = Ab[(int64_t)(g + 4 * i) * ld + 64 + c];
+    }
+    __syncthreads();
+    Acc64<T> x0, x1;
+    x0.zero(); mm64<T, 1>(x0, lv(B3), lvT(B0));
+    __syncthreads();                                                               // every wave is done with A0 (B3) and W00 (B0)
+    x0.foreach([&](int r, int cc, T v) { B3[r][cc] = v; });                        // X0 becomes an operand
+    {
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) B0[g + 4 * i][c] = a1[i];                     // A1
+    }
+    __syncthreads();
+    x1.zero(); mm64<T>(x1, lv(B3), lvT(B1));                                       // X0 L10'
+    __syncthreads();
+    x1.foreach([&](int r, int cc, T v) { B3[r][cc] = B0[r][cc] - v; });            // T = A1 - X0 L10'
+    __syncthreads();
+    x1.zero(); mm64<T, 1>(x1, lv(B3), lvT(B2));
+    x0.foreach([&](int r, int cc, T v) { Ab[(int64_t)r * ld + cc] = v; });
+    x1.foreach([&](int r, int cc, T v) { Ab[(int64_t)r * ld + 64 + cc] = v; });
+}
+
 // the factors of the diagonal blocks, stashed by the step kernels, go to their place in M
 template <typename T>
 __global__ __launch_bounds__(256) void k_chol_unstash(T* __restrict__ M, int64_t ld, const T* __restrict__ stash, int nblk, int64_t sM, int64_t sS) {
@@ -706,63 +940,35 @@ static int chol_step_width() {
     static const int w = [] { const char* e = getenv("QPS_CHOL_STEP"); return (e && atoi(e) == 64) ? 64 : 128; }();
     return w;
 }
-// Depth-1 look-ahead for the 128-column steps (QPS_CHOL_LOOKAHEAD=1; round-3 review item 4).  Step k + 1 reads only the first 128 columns of what the
-// trailing update of step k writes, so that update is cut in two: the 128 columns the next step needs (main stream) and the rest, which runs on a second
-// stream beside the next step launch -- a launch of at most 62 workgroups, each a chain of single-CU latencies, that leaves three quarters of the chip idle.
-// One event each way per step.  The side stream and its events are per host thread and device (handles of a device driven from several threads do not share them).
-namespace {
-struct LookaheadLane { hipStream_t side = nullptr; hipEvent_t stepped = nullptr, rest_done = nullptr; };
-struct LookaheadPool {
-    LookaheadLane lane[kMaxDevices];
-    ~LookaheadPool() { for (auto& l : lane) { if (l.stepped) (void)hipEventDestroy(l.stepped); if (l.rest_done) (void)hipEventDestroy(l.rest_done); if (l.side) (void)hipStreamDestroy(l.side); } }
-    LookaheadLane* get(int dev) {
-        if (dev < 0 || dev >= kMaxDevices) return nullptr;
-        LookaheadLane& l = lane[dev];
-        if (!l.side) {
-            if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.stepped, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&l.rest_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        }
-        return &l;
-    }
-};
-thread_local LookaheadPool g_lookahead;
-bool chol_lookahead() { static const bool on = [] { const char* e = getenv("QPS_CHOL_LOOKAHEAD"); return e && atoi(e) != 0; }(); return on; }
-}  // namespace
+// QPS_CHOL_FUSED=0: the round-3 chain (every step launch factorises its own diagonal block before its panel rows)
+static bool chol_fused() { const char* e = getenv("QPS_CHOL_FUSED"); return !(e && atoi(e) == 0); }   // read per factorisation (a test switches it)
+
+// trailing updates of at least this many tiles leave the diagonal workgroup's XCD alone (QPS_CHOL_AVOID: 0 = never)
+static int chol_avoid_tiles() { const char* e = getenv("QPS_CHOL_AVOID"); const int v = e ? atoi(e) : 256; return v > 0 ? v : (1 << 30); }
 
 template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch, T* scratch) {
     (void)hipMemsetAsync(fail_dev, 0, sizeof(int) * batch, st);
     const int nblk = NP / 64;
     const int64_t sM = (int64_t)NP * NP, sD = (int64_t)nblk * 4096;
-    if (scratch && chol_step_width() == 128 && chol_lookahead() && batch == 1 && nblk >= 8) {
-        LookaheadLane* la = g_lookahead.get(current_device());
-        if (la) {
-            const int64_t sS = chol_scratch_elems(NP);
-            bool rest_pending = false;
-            for (int cb = 0; cb < nblk; cb += 2) {
-                const int w = (nblk - cb >= 2) ? 2 : 1;
-                const int rem = NP - (cb + w) * 64;
-                hipLaunchKernelGGL((k_chol_step<T>), dim3(rem > 0 ? rem / 64 : 1, batch), dim3(256), 0, st, M, (int64_t)NP, cb, w, rem / 64, dinv, scratch,
-                                   fail_dev, sM, sD, sS);
-                if (rem <= 0) break;
-                const T* A21 = M + (int64_t)(cb + w) * 64 * NP + cb * 64;
-                T* A22 = M + (int64_t)(cb + w) * 64 * NP + (cb + w) * 64;
-                const int head = std::min(128, rem), tail = rem - head;
-                if (tail > 0) (void)hipEventRecord(la->stepped, st);                      // the panel L21 of this step is complete
-                if (rest_pending) { (void)hipStreamWaitEvent(st, la->rest_done, 0); rest_pending = false; }   // the previous rest also wrote these 128 columns
-                // the 128 columns the next step reads: rows [0, rem) x columns [0, head), lower tiles
-                gemm<T>(st, rem, head, w * 64, T(-1), A21, NP, true, A21, NP, true, T(1), A22, NP, true, 1, 0, 0, 0, 0);
-                if (tail > 0) {   // the rest, beside the next step launch
-                    (void)hipStreamWaitEvent(la->side, la->stepped, 0);
-                    const T* A21t = A21 + (int64_t)head * NP;
-                    gemm<T>(la->side, tail, tail, w * 64, T(-1), A21t, NP, true, A21t, NP, true, T(1), A22 + (int64_t)head * NP + head, NP, true, 1, 0, 0, 0, 0);
-                    (void)hipEventRecord(la->rest_done, la->side);
-                    rest_pending = true;
-                }
-            }
-            if (rest_pending) (void)hipStreamWaitEvent(st, la->rest_done, 0);
-            hipLaunchKernelGGL((k_chol_unstash<T>), dim3((nblk + 1) / 2, 3, batch), dim3(256), 0, st, M, (int64_t)NP, scratch, nblk, sM, sS);
-            return;
+    if (scratch && chol_step_width() == 128 && chol_fused()) {
+        // diagonal block of step k + 1 inside the trailing-update launch of step k (k_chol_update_diag); the step launch forms panel rows only
+        const int64_t sS = chol_scratch_elems(NP);
+        const int64_t roff = sS - 64;                                              // the hand-off counter of a matrix sits behind its stash tiles
+        hipLaunchKernelGGL((k_chol_update_diag<T>), dim3(1, batch), dim3(256), 0, st, M, (int64_t)NP, 0, 0, nblk, 0, 0, dinv, scratch, roff, fail_dev, sM, sD, sS);
+        for (int cb = 0; cb + 2 <= nblk; cb += 2) {
+            const int rem = NP - (cb + 2) * 64;
+            if (rem <= 0) break;
+            hipLaunchKernelGGL((k_chol_panel<T>), dim3(rem / 64, batch), dim3(256), 0, st, M, (int64_t)NP, cb, dinv, scratch, sM, sD, sS);
+            const int g = rem / 64, nt = g * (g + 1) / 2 - 1;                      // lower tiles behind (0, 0)
+            // a trailing GEMM that fills the chip is kept off the diagonal workgroup's XCD -- unless it is so long that 8/7 of it exceeds the contended
+            // factorisation (fp64 beyond ~56 x 56 tiles: 102.7 against 94.2 us at 62 x 62)
+            const int avoid = (batch == 1 && nt >= chol_avoid_tiles() && (sizeof(T) == 4 || nt <= 1500)) ? 1 : 0;
+            const int ids = 1 + nt + (avoid ? nt / 7 + 2 : 0);
+            hipLaunchKernelGGL((k_chol_update_diag<T>), dim3(ids, batch), dim3(256), 0, st, M, (int64_t)NP, cb + 2, 128, nblk, g, avoid, dinv, scratch, roff,
+                               fail_dev, sM, sD, sS);
         }
+        hipLaunchKernelGGL((k_chol_unstash<T>), dim3((nblk + 1) / 2, 3, batch), dim3(256), 0, st, M, (int64_t)NP, scratch, nblk, sM, sS);
+        return;
     }
     if (scratch && chol_step_width() == 128) {
         const int64_t sS = chol_scratch_elems(NP);

@@ -159,7 +159,7 @@ template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T 
 // the 64 x 64 diagonal blocks (NP/64 blocks of 64*64).  fail_dev: int32, 0 or 1+index of the failing pivot.
 // scratch != nullptr: chol_scratch_elems(NP) elements per matrix (consecutive); selects the 128-column steps (one panel launch + one
 // GEMM launch per 128 columns).  Any buffer that is dead during the factorisation will do (the sweep matrix S, for instance).
-inline int64_t chol_scratch_elems(int NP) { return (int64_t)((NP / 64 + 1) / 2) * 3 * 4096; }
+inline int64_t chol_scratch_elems(int NP) { return (int64_t)((NP / 64 + 1) / 2) * 3 * 4096 + 64; }   // stash tiles + the hand-off counter of k_chol_update_diag
 inline bool chol_scratch_fits(int NP) { return chol_scratch_elems(NP) <= (int64_t)NP * NP; }   // an NP x NP buffer is large enough (NP >= 128)
 template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* fail_dev, int batch = 1, T* scratch = nullptr);   // batch: matrices NP*NP apart
 

@@ -653,7 +653,7 @@ def test_register_resident_single_launch_kernel(gpu, c_oracle, dtype, n, m):
 
 KNOBS = [{"QPS_GRAPH": "0"}, {"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
          {"QPS_SMALL_REG": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"},
-         {"QPS_CHOL_STEP": "64"}, {"QPS_SWEEP_WAVE": "0"}]
+         {"QPS_CHOL_STEP": "64"}, {"QPS_CHOL_FUSED": "0"}, {"QPS_CHOL_AVOID": "1"}, {"QPS_SWEEP_WAVE": "0"}]
 
 
 @pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
