@@ -195,10 +195,13 @@ def rocprof_stats(config):
     return {}, None
 
 
-def kernel_list(ktimes, config=None, iters_per_s=None):
+def kernel_list(ktimes, config=None, iters_per_s=None, grid_y=None):
     """Per-kernel averages.  `avg_us` = HIP events attached to the sampled dispatches (they read ~1-2 us longer per launch than the kernel's own
     duration: the sum over an iteration's launches can exceed the wall time per iteration); `rocprof_avg_us` = the same kernel in the committed
-    rocprofv3 --kernel-trace --stats summary of this command, when one exists for the running sources."""
+    rocprofv3 kernel-trace summary of this command, when one exists for the running sources.  The summaries are made by tests/tools/trace_stats_split.py:
+    a kernel launched with several grids has one row per grid and the dispatches that returned at the CG `done` flag sit in a row of their own, so a figure
+    printed here is the average of launches that did this category's work.  grid_y: {category prefix: gridDim.y} picks the row of a category whose kernel
+    serves several categories (the two products of a CG iteration); a category that cannot be told apart gets no rocprof figure rather than a joint one."""
     rows, src = rocprof_stats(config) if config else ({}, None)
     out = []
     for k in ktimes:
@@ -206,13 +209,16 @@ def kernel_list(ktimes, config=None, iters_per_s=None):
              "GBs": round(k["algo_bytes"] / (k["seconds"] / k["launches"]) / 1e9, 1) if k["algo_bytes"] > 0 else None, "rocprof_avg_us": None}
         pat = next((rp for cp, rp in ROCPROF_NAME if re.search(cp, k["name"])), None)
         if pat and rows:
-            hit = [(n, v) for n, v in rows.items() if re.search(pat, n)]
+            hit = [(n, v) for n, v in rows.items() if re.search(pat, n) and "[returned at the done flag]" not in n]
+            gy = next((v for pre, v in (grid_y or {}).items() if k["name"].startswith(pre)), None)
+            if gy is not None and len(hit) > 1:
+                hit = [(n, v) for n, v in hit if re.search(r"\[grid \d+ x %d x \d+\]" % gy, n)]
             if hit:
                 name, (avg, calls) = max(hit, key=lambda t: t[1][1])
                 e["rocprof_avg_us"] = round(avg, 2)
                 e["_rocprof_kernel"] = name
         out.append(e)
-    # several categories served by ONE kernel name (the two products of a CG iteration): rocprofv3 cannot tell them apart, its figure is their joint average
+    # several categories left on ONE row (no per-grid rows in the summary, or equal grids): that row is their joint average -- not printed as either's
     seen = {}
     for e in out:
         if e.get("_rocprof_kernel"):
@@ -220,11 +226,12 @@ def kernel_list(ktimes, config=None, iters_per_s=None):
     for name, es in seen.items():
         if len(es) > 1:
             for e in es:
-                e["rocprof_note"] = f"joint average over {len(es)} categories that run the same kernel ({name.split('(')[0][:40]})"
+                e["rocprof_avg_us"] = None
+                e["rocprof_note"] = f"{len(es)} categories run the same kernel with the same grid ({name.split('(')[0][:40]}): the summary cannot tell them apart"
     for e in out:
         e.pop("_rocprof_kernel", None)
     if src:
-        out.append({"name": "_rocprof_source", "file": f"profiles/{src}"})
+        out.append({"name": "_rocprof_source", "file": f"profiles/{src}", "made_by": "tests/tools/trace_stats_split.py (per-grid rows, done-flag no-ops apart)"})
     return out
 
 
@@ -438,7 +445,8 @@ def run_sparse(args, cfg, info, device, qps, qd, np, sync):
         out["cg_iterations_per_admm_iteration"] = round(cg_per_admm, 2)
         out["loop_roofline"] = {"algo_bytes_per_cg_iteration": cg_bytes, "achieved_GBs": round(cg_bytes * cg["n"] / elapsed / 1e9, 1),
                                 "frac_of_8TBs": round(cg_bytes * cg["n"] / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
-        out["kernels"] = kernel_list(ktimes, "c3")
+        cb = 57344 // 8                                                   # columns per LDS-resident x block (spmv_layout.h), fp64
+        out["kernels"] = kernel_list(ktimes, "c3", grid_y={"spmv_blk([P;A]": -(-n // cb), "spmv_blk(A'": -(-m // cb)})
         out["cpu_baseline"], out["parity"] = None, None
         if not args.no_cpu_baseline and info.world_size == 1:
             out["cpu_baseline"], ref = cpu_baseline_sparse(P, q, A, l, u)

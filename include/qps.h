@@ -58,10 +58,16 @@ typedef enum {
                                    sizes (qps_linsys_auto: KKT_LDL or CG), CG when the direct factor does not fit the device plugin */
     QPS_LINSYS_CHOLESKY = 1,    /* reduced form P + sigma I + rho A'A, one Cholesky + two triangular sweeps / it   */
     QPS_LINSYS_CG = 2,          /* matrix-free CG on the reduced operator (LinearSystemSolvers.jl:145-186)         */
-    QPS_LINSYS_KKT_LDL = 3      /* sparse L D L' of the quasi-definite KKT matrix [P + sigma I  A'; A  -I/rho], the reference's
+    QPS_LINSYS_KKT_LDL = 3,     /* sparse L D L' of the quasi-definite KKT matrix [P + sigma I  A'; A  -I/rho], the reference's
                                    direct plugins LaLdl / QDLdl / FacLdl (LinearSystemSolvers.jl:16-107): minimum-degree ordering
                                    and symbolic factor once per handle, numeric-only re-factorisation on a rho switch, two
                                    level-scheduled sparse triangular solves per iteration.  CSC handles created with dense_path = 0 */
+    QPS_LINSYS_CG_EXPLICIT = 4  /* ItrSolCgInit / ItrSolCg! (LinearSystemSolvers.jl:110-142): cg! on the EXPLICIT reduced matrix mL = mPI + rho mAA,
+                                   mAA = mA'mA and mPI = mP + sigma I formed once per handle (:112-114), mL rebuilt from the cached parts on a rho switch
+                                   (:127-129), ONE product per CG iteration (:137).  CSC handles.  A QPS_LINSYS_CG (or AUTO -> CG) request takes this
+                                   plugin by itself when the matrix pays: mA'mA cheap to form and mL no larger than 1.5 x (nnz P + 2 nnz A) -- isotonic
+                                   regression, banded / control-like mA; otherwise, and always with QPS_CG_EXPLICIT=0 in the environment, it stays
+                                   matrix-free.  Same iterates up to rounding either way (the oracle restates both: linsys kinds 2 and 3) */
 } qps_linsys_kind;
 
 /* Keyword arguments of SolveQuadraticProgram! (SolveQuadraticProgram.jl:15-17), same names, same defaults.
@@ -125,7 +131,8 @@ typedef struct {
                                     workgroup inside the launch; trsvBlock = 1024 or 512 fp64, 2048 or 1024 fp32); 0 otherwise */
     int32_t sweepGaveUp;     /* times a variant-5 launch of this solve gave up waiting for its workgroups (only another PROCESS running the
                                 same kernel on the card can cause that) and the solve was repeated on variant 1; its time is in tLoop */
-    int32_t reserved1;
+    int32_t cgExplicit;      /* CSC handles, CG plugins: 1 = the solve ran cg! on the explicit reduced matrix (ItrSolCg, one product per CG iteration),
+                                0 = on the matrix-free operator (LinOpCg / LinMapsCg) or no CG at all */
 } qps_info;
 
 /* Fill *p with the reference defaults (SolveQuadraticProgram.jl:15-17). */
@@ -184,6 +191,21 @@ int32_t qps_linsys_solve(qps_handle h, const double *x, const double *z, const d
  * (LinearSystemSolvers.jl:125, :164, :207): inner tolerance (abstol of IterativeSolvers.cg!) and iteration cap used by the following
  * qps_linsys_solve calls of a CG handle.  Accepted and without effect on the direct plugins (they have no inner iteration). */
 int32_t qps_linsys_set_cg(qps_handle h, double epsPcg, int32_t numItrPcg);
+
+/* ONE application of the matrices behind the reduced operator of the CG plugins -- LinOpCgInit / LinMapsCgInit build it from three products,
+ *     mul!(vZZ, mA, vW); mul!(vU, mA', vZZ); mul!(vU, mP, vW, 1.0, rho); vU .+= sigma .* vW          LinearSystemSolvers.jl:152-157, :195-200
+ * and CheckConvergence applies the same three matrices to x and y (SolveQuadraticProgram.jl:85-89) -- through the device kernels qps_solve itself
+ * uses for them on this handle (CSC handles: the column-blocked SpMV when the handle built one, else the CSR-stream kernel; dense handles: the
+ * row / column GEMVs).  Host vector in, host vector out, in the handle's arithmetic type on the device:
+ *     QPS_OP_P        out[n]     = mP  * in[n]
+ *     QPS_OP_A        out[m]     = mA  * in[n]
+ *     QPS_OP_AT       out[n]     = mA' * in[m]
+ *     QPS_OP_PA       out[n + m] = [mP; mA] * in[n]   (the stacked product of a CG iteration: one pass over `in`)
+ *     QPS_OP_REDUCED  out[n]     = mP in + rho mA'(mA in) + sigma in                                    (:152-157; rho, sigma used by this one only)
+ * Additive (the reference has no such call): it lets a binding or a test compare the device copies of its matrices with its own product, one
+ * operator at a time.  The solver state (x, z, y of the last solve) is not touched. */
+typedef enum { QPS_OP_P = 0, QPS_OP_A = 1, QPS_OP_AT = 2, QPS_OP_PA = 3, QPS_OP_REDUCED = 4 } qps_operator_kind;
+int32_t qps_operator_apply(qps_handle h, int32_t op, const double *in, double *out, double rho, double sigma);
 
 /* Batch of `count` independent dense QPs of identical shape (BASELINE config 4).  Problem b uses
  * P + b*ldp*n ... i.e. arrays are stacked along a leading batch axis: P[count][n*n], A[count][m*n] (column-major

@@ -25,7 +25,7 @@ mutable struct QpsInfo
     rhoFinal::Float64; rhoProposed::Float64; resPrim::Float64; resDual::Float64
     tSetup::Float64; tLoop::Float64; tRefactor::Float64
     polishFlag::Int32; polishIterations::Int32; tPolish::Float64
-    trsvBlock::Int32; sweepVariant::Int32; sweepGaveUp::Int32; reserved1::Int32
+    trsvBlock::Int32; sweepVariant::Int32; sweepGaveUp::Int32; cgExplicit::Int32
     QpsInfo() = new(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1, 0, 0.0, 0, 0, 0, 0)
 end
 

@@ -9,7 +9,7 @@ import numpy as np
 import scipy.sparse as sp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libqps_oracle.so")
+_LIB_PATH = os.environ.get("QPS_ORACLE_LIB") or os.path.join(_HERE, "libqps_oracle.so")   # QPS_ORACLE_LIB: another build of the same file (the sanitizer one)
 
 KIND_RED_CHOL, KIND_KKT_LDL, KIND_CG_EXPLICIT, KIND_CG_MATFREE, KIND_KKT_LDL_SPARSE = 0, 1, 2, 3, 4
 
@@ -53,6 +53,8 @@ def available_cores() -> int:
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "qps_oracle.c")
+    if os.environ.get("QPS_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
     return _LIB_PATH

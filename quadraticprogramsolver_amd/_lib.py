@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
     "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
     "qps_proxqp_default_params", "qps_proxqp_create_dense", "qps_proxqp_init_kkt", "qps_proxqp_set_state", "qps_proxqp_get_state",
-    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze", "qps_proxqp_create_csc", "qps_linsys_set_cg",
+    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze", "qps_proxqp_create_csc", "qps_linsys_set_cg", "qps_operator_apply",
 ]
 
 QPS_OK = 0
@@ -28,7 +28,8 @@ STATUS_NAMES = {0: "QPS_OK", 1: "QPS_ERR_BAD_ARGUMENT", 2: "QPS_ERR_BAD_DIMENSIO
                 4: "QPS_ERR_FACTORIZATION", 5: "QPS_ERR_HIP", 6: "QPS_ERR_OUT_OF_MEMORY", 7: "QPS_ERR_NO_DEVICE",
                 8: "QPS_ERR_UNSUPPORTED"}
 QPS_F64, QPS_F32 = 0, 1
-QPS_LINSYS_AUTO, QPS_LINSYS_CHOLESKY, QPS_LINSYS_CG, QPS_LINSYS_KKT_LDL = 0, 1, 2, 3
+QPS_LINSYS_AUTO, QPS_LINSYS_CHOLESKY, QPS_LINSYS_CG, QPS_LINSYS_KKT_LDL, QPS_LINSYS_CG_EXPLICIT = 0, 1, 2, 3, 4
+QPS_OP_P, QPS_OP_A, QPS_OP_AT, QPS_OP_PA, QPS_OP_REDUCED = 0, 1, 2, 3, 4
 
 
 class QpsLibraryError(RuntimeError):
@@ -59,7 +60,7 @@ class QpsInfo(C.Structure):
                 ("cgIterations", C.c_int32), ("rhoFinal", C.c_double), ("rhoProposed", C.c_double),
                 ("resPrim", C.c_double), ("resDual", C.c_double), ("tSetup", C.c_double), ("tLoop", C.c_double),
                 ("tRefactor", C.c_double), ("polishFlag", C.c_int32), ("polishIterations", C.c_int32), ("tPolish", C.c_double),
-                ("trsvBlock", C.c_int32), ("sweepVariant", C.c_int32), ("sweepGaveUp", C.c_int32), ("reserved1", C.c_int32)]
+                ("trsvBlock", C.c_int32), ("sweepVariant", C.c_int32), ("sweepGaveUp", C.c_int32), ("cgExplicit", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -134,6 +135,7 @@ def lib() -> C.CDLL:
     L.qps_linsys_init.argtypes = [hp, dbl, dbl, i32, i32]
     L.qps_linsys_solve.argtypes = [hp, dp, dp, dp, dbl, dbl, i32, dp, dp]
     L.qps_linsys_set_cg.argtypes = [hp, dbl, i32]
+    L.qps_operator_apply.argtypes = [hp, i32, dp, dp, dbl, dbl]
     L.qps_create_dense_batch.argtypes = [i64, i64, i64, dp, dp, dp, dp, dp, i32, i32, C.POINTER(hp)]
     L.qps_solve_batch.argtypes = [hp, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo)]
     L.qps_kernel_times.argtypes = [hp, C.POINTER(QpsKernelTime), i32, C.POINTER(i32)]

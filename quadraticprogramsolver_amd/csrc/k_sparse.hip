@@ -21,6 +21,7 @@
 #include "qps_proxqp.h"
 #include "k_proxqp_rows.h"
 #include "wave_reduce.h"
+#include "spmv_layout.h"
 #include <hip/hip_ext.h>
 
 namespace qps {
@@ -28,7 +29,7 @@ namespace qps {
 namespace {
 
 struct CgState { double res2, prev2, tol, uc; int iters, done, maxiter, pad; };   // two copies, ping-ponged per CG iteration
-constexpr int STREAM_NNZ = 1024;   // non-zeros streamed per workgroup (256 threads x 4)
+using layout::STREAM_NNZ;           // non-zeros streamed per workgroup (256 threads x 4); the layouts themselves are built in spmv_layout.cpp
 
 __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     v = wave_sum_all(v);
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int* __restrict__ rb,
 // of the block) with unit-stride loads and gathers from LDS.  Row sums per block go to partial[b][row]; k_spmv_combine
 // adds the blocks in fixed order and applies the epilogue (scale, two axpys, optional dot partials).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int BCHUNK = 2048;          // non-zeros per task (512 threads x 4)
-constexpr int BTHREADS = 512;
-template <typename T> struct BlkOf { static constexpr int CB = (int)(57344 / sizeof(T)); };   // 56 KiB of x + 16 KiB of products: two workgroups per CU
+using layout::BCHUNK;                 // non-zeros per task (512 threads x 4)
+using layout::BTHREADS;
+template <typename T> struct BlkOf { static constexpr int CB = layout::cb_of<T>(); };   // 56 KiB of x + 16 KiB of products: two workgroups per CU
 
 
 // four consecutive values as aligned 16-byte accesses, register to register (no pointer casts of local arrays: those end up in scratch)
@@ -144,7 +145,7 @@ __device__ int g_spmv_stamp_rows = 0;
 #endif
 
 // (rows per task: at most 4 passes x (BTHREADS / LPR) rows = 512 or 256 -- the builder's `max_rows`; their row pointers are staged in LDS)
-constexpr int BMAXT = 64;             // tasks per workgroup at most (their descriptors are staged in LDS)
+using layout::BMAXT;                  // tasks per workgroup at most (their descriptors are staged in LDS)
 // Optional fusion of the CG direction update into the x-block load of the operator's first product:  u_new = r + beta u_old,
 // beta from the ||r||^2 partials of the previous iteration; block (0,0) publishes the scalars (what k_cg_next_u does).
 // u_new goes to a second buffer (other workgroups of the same column block still read u_old).
@@ -375,14 +376,15 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_blk(int nrows, int ncols, con
 // (Tried and dropped: slices handed out one ticket at a time from a per-block atomic counter, to even out the workgroups' lifetimes -- ~600 waves
 // adding to one address serialise at ~80 ns each: 240 us per product instead of 27.  Non-temporal loads of the matrix: no difference.)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int SIGMA = 2048;           // sorting window (rows).  8192 measured: slice padding on BASELINE config 3 5.2 % -> 1.4 % of the entries (pair rounding: 7 % either
+using layout::SIGMA;                  // sorting window (rows), 2048.  8192 measured: slice padding on BASELINE config 3 5.2 % -> 1.4 % of the entries (pair rounding: 7 % either
                                       // way), products 27.9 / 17.1 -> 33.4 / 18.9 us -- the row sums of a slice then scatter over 64 KB of the partial sums instead of 16 KB
-constexpr int SLONG = 96;             // more entries than this in one block: the row is summed by a wave of its own
+using layout::SLONG;                  // more entries than this in one block: the row is summed by a wave of its own
 constexpr int SU = 4;                 // units of a slice in flight per batch (8: same time -- the launch is not bound by round trips per slice)
 struct SellDims { int nrows, ncols, nsl, wpb; };   // nsl = slices per column block
 template <typename T> struct SellOf;
-template <> struct SellOf<double> { static constexpr int E = 2; using CV = unsigned; };
-template <> struct SellOf<float> { static constexpr int E = 4; using CV = uint2; };
+template <> struct SellOf<double> { static constexpr int E = layout::sell_e<double>(); using CV = unsigned; };
+template <> struct SellOf<float> { static constexpr int E = layout::sell_e<float>(); using CV = uint2; };
+static_assert(sizeof(int4) == sizeof(layout::Int4), "descriptors are uploaded as the host builder lays them out");
 __device__ __forceinline__ void sell_cols(unsigned p, int (&c)[2]) { c[0] = (int)(p & 0xffffu); c[1] = (int)(p >> 16); }
 __device__ __forceinline__ void sell_cols(uint2 p, int (&c)[4]) { c[0] = (int)(p.x & 0xffffu); c[1] = (int)(p.x >> 16); c[2] = (int)(p.y & 0xffffu); c[3] = (int)(p.y >> 16); }
 __device__ __forceinline__ void sell_vals(double2 v, double (&o)[2]) { o[0] = v.x; o[1] = v.y; }
@@ -677,6 +679,19 @@ __global__ __launch_bounds__(256) void k_axpby(int n, T a, const T* __restrict__
     if (i < n) out[i] = a * x[i] + b * y[i];
 }
 
+// mL = mPI + rho * mAA on the frozen pattern of the explicit reduced matrix: out = vP + sigma * diag + rho * vAA   (LinearSystemSolvers.jl:113-114, :128)
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_reduced(int64_t nnz, const T* __restrict__ vP, const T* __restrict__ vAA, const T* __restrict__ dg, T sigma, T rho, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nnz) out[i] = vP[i] + sigma * dg[i] + rho * vAA[i];
+}
+// values of a column-blocked copy refreshed from the CSR values they were laid out from: dst[i] = va[src[i]] (src < 0: padding, stays 0)
+template <typename T>
+__global__ __launch_bounds__(256) void k_refresh_values(int64_t count, const int* __restrict__ src, const T* __restrict__ va, T* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) { const int k = src[i]; dst[i] = k >= 0 ? va[k] : T(0); }
+}
+
 struct Csr {
     int nrows = 0; int64_t nnz = 0; int* rp = nullptr; int* ci = nullptr; void* va = nullptr; int* rb = nullptr; int nblocks = 0;
     // column-blocked copy (k_spmv_blk): nblk CSR blocks back to back; used when `blocked`
@@ -685,15 +700,21 @@ struct Csr {
     int* lr_ptr = nullptr; int4* lr_desc = nullptr;   // rows with more than BCHUNK entries in one block: (row, first entry, end entry, 0), [nblk + 1] ranges
     // sliced form (k_spmv_sell): units of 64 lanes x E entries; bci / bva then hold only the long rows' entries
     bool sell = false; int nsl = 0; int* wg_ptr = nullptr; int* sl_off = nullptr; unsigned short* sl_perm = nullptr; void* s_cols = nullptr; void* s_vals = nullptr;
+    // value refresh of a matrix with a frozen pattern (the explicit reduced matrix): where every slot of s_vals / bva came from in `va`
+    int* src = nullptr; int64_t src_n = 0; int* lsrc = nullptr; int64_t lsrc_n = 0;
 };
 
 template <typename T> struct SparseSolver : SolverBase {
     HandleResources res; std::unique_ptr<StagedUploader> up;   // `up` lives for the duration of the constructor only
     Csr A, At, P, PA;   // PA = [P; A] stacked, column-blocked only: P u and A u of the CG operator from ONE pass over u
+    // ItrSolCgInit / ItrSolCg! (LinearSystemSolvers.jl:110-142): the explicit reduced matrix mL = mPI + rho mAA on a frozen pattern; ONE product per CG iteration
+    Csr Lm; T *L_vP = nullptr, *L_vAA = nullptr, *L_dg = nullptr;
+    int explicit_state = 0;          // 0 undecided, 1 built, -1 declined (too dense to pay, or its inputs were released)
+    bool cg_explicit = false; bool L_valid = false; double L_rho = 0, L_sigma = 0; int num_L_builds = 0;
     T *q = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *xp = nullptr, *z = nullptr, *zp = nullptr, *y = nullptr;
     T *xx = nullptr, *zz = nullptr, *w = nullptr, *tt = nullptr, *cu = nullptr, *cu2 = nullptr, *cr = nullptr, *cc = nullptr, *tm = nullptr;
     T *Ax = nullptr, *Px = nullptr, *Aty = nullptr;
-    double *part_uc = nullptr, *part_rr = nullptr; CgState* state = nullptr; CgState* state_host = nullptr;
+    double *part_uc = nullptr, *part_rr = nullptr; int part_uc_cap = 0; CgState* state = nullptr; CgState* state_host = nullptr;
     unsigned long long* scratch = nullptr; double* res_dev = nullptr; double* res_host = nullptr; double* stage = nullptr;
     int nb_n = 0, nb_op = 0; int64_t cg_total = 0; int last_cg = 4;
     double eps_pcg = 1e-6; int itr_pcg = 1000;
@@ -723,209 +744,58 @@ template <typename T> struct SparseSolver : SolverBase {
         return exec;
     }
 
-    // sliced form of the column-blocked copy (k_spmv_sell): rows sorted by their length in the block inside windows of SIGMA rows, slices of 64 rows
-    // padded to their longest row, stored unit by unit (64 lanes x E entries); rows longer than SLONG in a block go to the long-row list
-    bool build_sell(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
-        constexpr int CB = BlkOf<T>::CB, E = SellOf<T>::E;
-        const int nrows = M.nrows, nblk = (ncols + CB - 1) / CB;
-        const int nwin = (nrows + SIGMA - 1) / SIGMA;
-        const int nsl = (nwin - 1) * (SIGMA / 64) + ((nrows - (nwin - 1) * SIGMA) + 63) / 64;      // slices per block (only the last window is short)
-        if ((int64_t)nblk * nsl * 64 > 2000000000LL) return false;
-        // block-wise row pointers
-        std::vector<int> brp((size_t)nblk * (nrows + 1), 0);
-        for (int r = 0; r < nrows; ++r)
-            for (int k = rp[r]; k < rp[r + 1]; ++k) brp[(size_t)(ci[k] / CB) * (nrows + 1) + r + 1]++;
-        for (int b = 0; b < nblk; ++b) { int* q_ = &brp[(size_t)b * (nrows + 1)]; for (int r = 0; r < nrows; ++r) q_[r + 1] += q_[r]; }
-        // entries of block b, row r: column indices are sorted inside a row, so they are the run [first[b][r], first[b][r] + len) of the row
-        std::vector<int> first((size_t)nblk * nrows, 0);
-        for (int r = 0; r < nrows; ++r) {
-            int k = rp[r];
-            for (int b = 0; b < nblk; ++b) { first[(size_t)b * nrows + r] = k; k += brp[(size_t)b * (nrows + 1) + r + 1] - brp[(size_t)b * (nrows + 1) + r]; }
-        }
-        std::vector<int> sl_off((size_t)nblk * nsl + 1, 0), lptr(nblk + 1, 0); std::vector<int4> lr;
-        std::vector<unsigned short> perm((size_t)nblk * nsl * 64, (unsigned short)0xffff);
-        std::vector<unsigned short> cols, lci; std::vector<T> vals, lva;
-        cols.reserve((size_t)(M.nnz + M.nnz / 8)); vals.reserve((size_t)(M.nnz + M.nnz / 8));
-        int64_t units = 0;
-        std::vector<std::pair<int, int>> ord;                        // (length, row) of one window
-        for (int b = 0; b < nblk; ++b) {
-            const int* q_ = &brp[(size_t)b * (nrows + 1)];
-            for (int w = 0; w < nwin; ++w) {
-                const int r0 = w * SIGMA, r1 = std::min(nrows, r0 + SIGMA);
-                ord.clear();
-                for (int r = r0; r < r1; ++r) {
-                    const int L = q_[r + 1] - q_[r];
-                    if (L > SLONG) {                                 // summed by a wave of its own, not stored by a slice
-                        const int k0 = first[(size_t)b * nrows + r];
-                        lr.push_back(make_int4(r, (int)lci.size(), (int)lci.size() + L, 0));
-                        for (int k = 0; k < L; ++k) { lci.push_back((unsigned short)(ci[k0 + k] - b * CB)); lva.push_back((T)va[k0 + k]); }
-                        continue;
-                    }
-                    ord.emplace_back(L, r);
-                }
-                std::stable_sort(ord.begin(), ord.end(), [](const std::pair<int, int>& x_, const std::pair<int, int>& y_) { return x_.first > y_.first; });
-                const int wsl = (r1 - r0 + 63) / 64;                 // slices of this window (long rows leave lanes without a row at its end)
-                for (int sl = 0; sl < wsl; ++sl) {
-                    const int64_t g = (int64_t)b * nsl + (int64_t)w * (SIGMA / 64) + sl;
-                    sl_off[g] = (int)units;
-                    const int p0 = sl * 64;
-                    const int L = p0 < (int)ord.size() ? ord[p0].first : 0, nu = (L + E - 1) / E;
-                    for (int lane = 0; lane < 64; ++lane) if (p0 + lane < (int)ord.size()) perm[g * 64 + lane] = (unsigned short)(ord[p0 + lane].second - r0);
-                    const size_t base = cols.size();
-                    cols.resize(base + (size_t)nu * 64 * E, (unsigned short)CB); vals.resize(base + (size_t)nu * 64 * E, T(0));
-                    for (int lane = 0; lane < 64 && p0 + lane < (int)ord.size(); ++lane) {
-                        const int len = ord[p0 + lane].first, k0 = first[(size_t)b * nrows + ord[p0 + lane].second];
-                        for (int j = 0; j < len; ++j) {
-                            const size_t at = base + ((size_t)(j / E) * 64 + lane) * E + (j % E);
-                            cols[at] = (unsigned short)(ci[k0 + j] - b * CB); vals[at] = (T)va[k0 + j];
-                        }
-                    }
-                    units += nu;
-                    if (units > 30000000LL) return false;            // int32 unit offsets x 64 lanes: leave such matrices to the task form
-                }
-            }
-            lptr[b + 1] = (int)lr.size();
-        }
-        sl_off[(size_t)nblk * nsl] = (int)units;
-        static const int wgs_env = [] { const char* e = getenv("QPS_SPMV_WGS"); return e ? atoi(e) : 0; }();
-        const int wgs = wgs_env > 0 ? wgs_env : 512;
-        M.ncols = ncols; M.nblk = nblk; M.nsl = nsl;
-        M.wpb = std::max(1, std::min(nsl, wgs / nblk));              // floor: a launch of at most `wgs` workgroups is resident at once (2 per CU)
-        std::vector<int> wg_ptr((size_t)nblk * (M.wpb + 1), 0);
-        for (int b = 0; b < nblk; ++b) {                             // slice ranges of equal cost (units + a fixed part per slice)
-            const int* so = &sl_off[(size_t)b * nsl];
-            const int64_t tot = (int64_t)(so[nsl] - so[0]) + 2 * (int64_t)nsl;
-            int* wp = &wg_ptr[(size_t)b * (M.wpb + 1)];
-            int w = 1;
-            for (int sl = 0; sl < nsl; ++sl) {
-                const int64_t run_ = (int64_t)(so[sl + 1] - so[0]) + 2 * (int64_t)(sl + 1);
-                while (w < M.wpb && run_ * M.wpb >= tot * w) wp[w++] = sl + 1;
-            }
-            while (w <= M.wpb) wp[w++] = nsl;
-        }
-        cols.resize(cols.size() + 64 * E, (unsigned short)CB); vals.resize(vals.size() + 64 * E, T(0));   // a slice without units still reads one
-        lci.resize(lci.size() + 64, 0); lva.resize(lva.size() + 64, T(0));
-        M.s_cols = dalloc<unsigned short>((int64_t)cols.size(), st); M.s_vals = dalloc<T>((int64_t)vals.size(), st);
-        M.bci = dalloc<unsigned short>((int64_t)lci.size(), st); M.bva = dalloc<T>((int64_t)lva.size(), st);
-        M.sl_off = dalloc<int>((int64_t)sl_off.size(), st); M.sl_perm = dalloc<unsigned short>((int64_t)perm.size(), st);
-        M.wg_ptr = dalloc<int>((int64_t)wg_ptr.size(), st); M.lr_ptr = dalloc<int>(nblk + 1, st); M.lr_desc = dalloc<int4>((int64_t)lr.size() + 1, st);
-        M.partial = dalloc<T>((int64_t)nblk * nrows + 64, st);
-        up->copy(M.s_cols, cols.data(), sizeof(unsigned short) * cols.size());
-        up->copy(M.s_vals, vals.data(), sizeof(T) * vals.size());
-        up->copy(M.bci, lci.data(), sizeof(unsigned short) * lci.size());
-        up->copy(M.bva, lva.data(), sizeof(T) * lva.size());
-        up->copy(M.sl_off, sl_off.data(), sizeof(int) * sl_off.size());
-        up->copy(M.sl_perm, perm.data(), sizeof(unsigned short) * perm.size());
-        up->copy(M.wg_ptr, wg_ptr.data(), sizeof(int) * wg_ptr.size());
-        up->copy(M.lr_ptr, lptr.data(), sizeof(int) * lptr.size());
-        if (!lr.empty()) up->copy(M.lr_desc, lr.data(), sizeof(int4) * lr.size());
-        M.blocked = true; M.sell = true;
-        return true;
+    // Column-blocked copy of M: the sliced form (k_spmv_sell) when the host builder produces one, else the task form (k_spmv_blk).  The layouts are
+    // built by plain host code (spmv_layout.cpp, tested on the CPU against scipy); here they are only uploaded.
+    template <typename V> V* upload_array(const std::vector<V>& v, int64_t min_count = 1) {
+        V* d = dalloc<V>(std::max<int64_t>((int64_t)v.size(), min_count), st);
+        if (!v.empty()) up->copy(d, v.data(), sizeof(V) * v.size());
+        return d;
     }
-    // column-blocked copy for k_spmv_blk: per block a CSR with 16-bit local column indices + its task list
-    void build_blocked(Csr& M, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
-        constexpr int CB = BlkOf<T>::CB;
-        const int nrows = M.nrows, nblk = (ncols + CB - 1) / CB;
-        {
-            const char* e = getenv("QPS_SPMV_SELL");                 // read per handle: 0 = the task form (k_spmv_blk)
-            if (!(e && atoi(e) == 0) && build_sell(M, ncols, rp, ci, va)) return;
-        }
-        // per block: entries per row, then the tasks (consecutive rows holding <= BCHUNK entries, <= BROWS - 1 rows; a longer row stands alone), then
-        // the offsets -- every TASK starts at a multiple of four entries (the kernel reads four consecutive entries per thread with aligned 8- and
-        // 16-byte loads); the gap in front of it holds zero entries, which the last row of the previous task sums up harmlessly
-        std::vector<int> brp((size_t)nblk * (nrows + 1), 0);
-        for (int r = 0; r < nrows; ++r)
-            for (int k = rp[r]; k < rp[r + 1]; ++k) brp[(size_t)(ci[k] / CB) * (nrows + 1) + r + 1]++;
-        std::vector<int> tptr(nblk + 1, 0), lptr(nblk + 1, 0); std::vector<int4> tk, lr;
-        // lanes per row segment: 4 while a row holds <= ~8 entries per block on average, else 8; a task's rows are summed in ONE group of four passes
-        const int lpr4 = (M.nnz <= (int64_t)8 * nrows * nblk) ? 1 : 0;
-        const int max_rows = 4 * (BTHREADS / (lpr4 ? 4 : 8));        // 512 / 256 rows per task at most (k_spmv_blk: RPP * PG)
-        int64_t run = 0;                                             // blocks back to back, rows in order inside a block
-        auto align4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
-        for (int b = 0; b < nblk; ++b) {
-            int* q_ = &brp[(size_t)b * (nrows + 1)];
-            std::vector<int> cnt(q_ + 1, q_ + nrows + 1);
-            int64_t acc = align4(run); int start = 0; int64_t tnnz = 0;
-            q_[0] = (int)acc;
-            for (int r = 0; r < nrows; ++r) {
-                const bool alone = cnt[r] > BCHUNK;
-                if (r > start && (alone || tnnz + cnt[r] > BCHUNK || r - start >= max_rows)) {        // close [start, r)
-                    const int64_t e_ = align4(acc);
-                    tk.push_back(make_int4(start, r, q_[start], (int)e_));
-                    acc = e_; start = r; tnnz = 0;
-                }
-                q_[r] = (int)acc; acc += cnt[r]; tnnz += cnt[r];
-                if (alone) {                                         // a row longer than a task: summed by a whole workgroup behind the tasks
-                    const int64_t e_ = align4(acc);
-                    lr.push_back(make_int4(r, q_[r], (int)acc, 0));
-                    acc = e_; start = r + 1; tnnz = 0;
-                }
-            }
-            const int64_t e_ = align4(acc);
-            if (start < nrows) tk.push_back(make_int4(start, nrows, q_[start], (int)e_));
-            q_[nrows] = (int)e_;
-            run = e_;
-            tptr[b + 1] = (int)tk.size(); lptr[b + 1] = (int)lr.size();
-        }
-        if (run + 64 > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 entries in the column-blocked copy");
-        std::vector<unsigned short> bci((size_t)run + 64, 0);
-        std::vector<T> bva((size_t)run + 64, T(0));
-        {
-            std::vector<int> pos((size_t)nblk * nrows);
-            for (int b = 0; b < nblk; ++b) for (int r = 0; r < nrows; ++r) pos[(size_t)b * nrows + r] = brp[(size_t)b * (nrows + 1) + r];
-            for (int r = 0; r < nrows; ++r)
-                for (int k = rp[r]; k < rp[r + 1]; ++k) {
-                    const int b = ci[k] / CB; int& w_ = pos[(size_t)b * nrows + r];
-                    bci[w_] = (unsigned short)(ci[k] - b * CB); bva[w_] = (T)va[k]; ++w_;
-                }
-        }
+    void build_blocked(Csr& M, const layout::CsrHost& H, bool with_src = false) {
         static const int wgs_env = [] { const char* e = getenv("QPS_SPMV_WGS"); return e ? atoi(e) : 0; }();
         const int wgs = wgs_env > 0 ? wgs_env : 512;
-        M.ncols = ncols; M.nblk = nblk;
-        int maxt = 1; for (int b = 0; b < nblk; ++b) maxt = std::max(maxt, tptr[b + 1] - tptr[b]);
-        M.wpb = std::max(1, std::min(maxt, (wgs + nblk - 1) / nblk));   // about two workgroups per CU over the launch
-        M.wpb = std::max(M.wpb, (maxt + BMAXT - 1) / BMAXT);            // at most BMAXT tasks per workgroup
-        M.per = (maxt + M.wpb - 1) / M.wpb;
-        M.lpr4 = lpr4;
-        M.brp = dalloc<int>((int64_t)brp.size(), st); M.bci = dalloc<unsigned short>((int64_t)bci.size(), st); M.bva = dalloc<T>((int64_t)bva.size(), st);
-        M.task_ptr = dalloc<int>(nblk + 1, st); M.tasks = dalloc<int4>((int64_t)tk.size() + 1, st);
-        M.lr_ptr = dalloc<int>(nblk + 1, st); M.lr_desc = dalloc<int4>((int64_t)lr.size() + 1, st);
-        up->copy(M.lr_ptr, lptr.data(), sizeof(int) * lptr.size());
-        if (!lr.empty()) up->copy(M.lr_desc, lr.data(), sizeof(int4) * lr.size());
-        M.partial = dalloc<T>((int64_t)nblk * nrows + 64, st);          // + 64: the dump slots of lanes without a row
-        up->copy(M.brp, brp.data(), sizeof(int) * brp.size());
-        up->copy(M.bci, bci.data(), sizeof(unsigned short) * bci.size());
-        up->copy(M.bva, bva.data(), sizeof(T) * bva.size());
-        up->copy(M.task_ptr, tptr.data(), sizeof(int) * tptr.size());
-        if (!tk.empty()) up->copy(M.tasks, tk.data(), sizeof(int4) * tk.size());
+        M.ncols = H.ncols;
+        const char* e = getenv("QPS_SPMV_SELL");                     // read per handle: 0 = the task form (k_spmv_blk)
+        if (!(e && atoi(e) == 0)) {
+            layout::SellLayout<T> L;
+            if (layout::build_sell<T>(H, wgs, L, with_src)) {
+                M.nblk = L.nblk; M.nsl = L.nsl; M.wpb = L.wpb;
+                if (with_src) { M.src = upload_array(L.src); M.src_n = (int64_t)L.src.size(); M.lsrc = upload_array(L.lsrc); M.lsrc_n = (int64_t)L.lsrc.size(); }
+                M.s_cols = upload_array(L.cols); M.s_vals = upload_array(L.vals);
+                M.bci = upload_array(L.lci); M.bva = upload_array(L.lva);
+                M.sl_off = upload_array(L.sl_off); M.sl_perm = upload_array(L.perm); M.wg_ptr = upload_array(L.wg_ptr);
+                M.lr_ptr = upload_array(L.lr_ptr); M.lr_desc = reinterpret_cast<int4*>(upload_array(L.lr));
+                M.partial = dalloc<T>((int64_t)L.nblk * H.nrows + 64, st);
+                M.blocked = true; M.sell = true;
+                return;
+            }
+        }
+        layout::TaskLayout<T> L;
+        try { layout::build_tasks<T>(H, wgs, L, with_src); }
+        catch (const std::length_error& ex) { throw QpsError(QPS_ERR_BAD_DIMENSION, ex.what()); }
+        M.nblk = L.nblk; M.wpb = L.wpb; M.per = L.per; M.lpr4 = L.lpr4;
+        if (with_src) { M.src = upload_array(L.src); M.src_n = (int64_t)L.src.size(); }
+        M.brp = upload_array(L.brp); M.bci = upload_array(L.bci); M.bva = upload_array(L.bva);
+        M.task_ptr = upload_array(L.task_ptr); M.tasks = reinterpret_cast<int4*>(upload_array(L.tasks));
+        M.lr_ptr = upload_array(L.lr_ptr); M.lr_desc = reinterpret_cast<int4*>(upload_array(L.lr));
+        M.partial = dalloc<T>((int64_t)L.nblk * H.nrows + 64, st);    // + 64: the dump slots of lanes without a row
         M.blocked = true;
     }
-    void upload_csr(Csr& M, int nrows, int ncols, const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& va) {
-        M.nrows = nrows; M.nnz = (int64_t)ci.size();
+    void upload_csr(Csr& M, const layout::CsrHost& H, bool with_src = false) {
+        M.nrows = H.nrows; M.nnz = (int64_t)H.ci.size();
         {   // LDS-resident x pays once the gathers dominate; QPS_SPMV_BLOCKED = 1 / 0 forces the choice
             const char* e = getenv("QPS_SPMV_BLOCKED");
             const bool want = e ? atoi(e) != 0 : M.nnz >= 200000;
-            if (want && nrows > 0 && ncols > 0) build_blocked(M, ncols, rp, ci, va);
+            if (want && H.nrows > 0 && H.ncols > 0) build_blocked(M, H, with_src);
         }
-        M.rp = dalloc<int>(nrows + 1, st); M.ci = dalloc<int>(M.nnz, st); M.va = dalloc<T>(M.nnz, st);
-        up->copy(M.rp, rp.data(), sizeof(int) * (nrows + 1));
-        {   // row blocks of the CSR-stream kernel: consecutive rows with <= STREAM_NNZ non-zeros; a longer row stands alone
-            std::vector<int> rbv(1, 0);
-            int start = 0;
-            for (int r = 0; r < nrows; ++r) {
-                if (rp[r + 1] - rp[start] > STREAM_NNZ && r > start) { rbv.push_back(r); start = r; }
-                if (rp[r + 1] - rp[start] > STREAM_NNZ) { rbv.push_back(r + 1); start = r + 1; }   // single long row
-            }
-            if (start < nrows) rbv.push_back(nrows);
-            M.nblocks = (int)rbv.size() - 1;
-            M.rb = dalloc<int>((int64_t)rbv.size(), st);
-            up->copy(M.rb, rbv.data(), sizeof(int) * rbv.size());
+        M.rp = upload_array(H.rp); M.ci = upload_array(H.ci);
+        {
+            std::vector<T> v(H.va.begin(), H.va.end());
+            M.va = upload_array(v);
         }
-        if (M.nnz > 0) {
-            up->copy(M.ci, ci.data(), sizeof(int) * M.nnz);
-            std::vector<T> v(va.begin(), va.end());
-            up->copy(M.va, v.data(), sizeof(T) * M.nnz);
-        }
+        const std::vector<int> rbv = layout::stream_row_blocks(H);   // row blocks of the CSR-stream kernel
+        M.nblocks = (int)rbv.size() - 1;
+        M.rb = upload_array(rbv);
     }
     void upload_vec(const double* h, T* d, int64_t count) {
         if (count <= 0) return;
@@ -939,35 +809,74 @@ template <typename T> struct SparseSolver : SolverBase {
         HIPC(hipMemcpyAsync(h, stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
     }
-    static void canonical_csc(int ncols, const int64_t* cp, const int64_t* ri, const double* nz, int base, std::vector<int64_t>& ocp,
-                              std::vector<int64_t>& ori, std::vector<double>& onz) {
-        ocp.assign(ncols + 1, 0); ori.clear(); onz.clear();
-        ori.reserve((size_t)(cp[ncols] - base)); onz.reserve((size_t)(cp[ncols] - base));
-        std::vector<std::pair<int64_t, double>> col;
-        for (int j = 0; j < ncols; ++j) {
-            col.clear();
-            for (int64_t k = cp[j] - base; k < cp[j + 1] - base; ++k) col.emplace_back(ri[k] - base, nz[k]);
-            auto less = [](const std::pair<int64_t, double>& a, const std::pair<int64_t, double>& b) { return a.first < b.first; };
-            if (!std::is_sorted(col.begin(), col.end(), less)) std::stable_sort(col.begin(), col.end(), less);
-            for (size_t k = 0; k < col.size(); ++k) {
-                if ((int64_t)ori.size() > ocp[j] && ori.back() == col[k].first) onz.back() += col[k].second;
-                else { ori.push_back(col[k].first); onz.push_back(col[k].second); }
-            }
-            ocp[j + 1] = (int64_t)ori.size();
+    // ItrSolCgInit (LinearSystemSolvers.jl:110-122): mAA = mA' * mA, mPI = mP + sigma I, mL = mPI + rho * mAA, formed on the host ONCE per handle as three value
+    // arrays on the frozen pattern of mL (spmv_layout.cpp: reduced_matrix); returns whether the handle has it.  forced = an explicit QPS_LINSYS_CG_EXPLICIT request;
+    // otherwise the matrix is only formed when it pays -- A'A cheap to form (sum of squared row lengths) and mL no larger than 1.5 x the entries the matrix-free
+    // operator streams per application (nnz P + 2 nnz A).  BASELINE config 3 (unstructured, ~50 entries per row) fails the first test in O(m) and stays matrix-free.
+    bool explicit_prepare(bool forced) {
+        if (explicit_state != 0) {
+            if (forced && explicit_state < 0) throw QpsError(QPS_ERR_UNSUPPORTED, "QPS_LINSYS_CG_EXPLICIT: the reduced matrix of this handle cannot be formed (too many entries, or the handle's "
+                                                                                  "host copies were released to the direct plugin before the first CG request)");
+            return explicit_state > 0;
         }
+        explicit_state = -1;
+        if (hPcp.empty() || hAcp.empty()) { if (forced) return explicit_prepare(true); return false; }   // released (the L D L' plugin was built first)
+        const int64_t pnnz = (int64_t)hPri.size(), annz = (int64_t)hAri.size();
+        layout::CsrHost Ph, Ah, Ath, Lh; std::vector<double> vAA, dg;
+        try {
+            Ph = layout::csc_as_transposed_csr(n, n, hPcp, hPri, hPnz);
+            layout::csc_to_csr_pair(m, n, hAcp, hAri, hAnz, Ah, Ath);
+            if (!forced && layout::ata_work(Ah) > 16 * (pnnz + annz)) return false;
+            const int64_t cap = forced ? 1900000000LL : (3 * (pnnz + 2 * annz)) / 2 + n;
+            if (!layout::reduced_matrix(Ph, Ah, Ath, cap, Lh, vAA, dg)) { if (forced) return explicit_prepare(true); return false; }
+        } catch (const std::length_error& ex) { throw QpsError(QPS_ERR_BAD_DIMENSION, ex.what()); }
+        up.reset(new StagedUploader(st));
+        upload_csr(Lm, Lh, true);
+        std::vector<T> t1(Lh.va.begin(), Lh.va.end()), t2(vAA.begin(), vAA.end()), t3(dg.begin(), dg.end());
+        L_vP = upload_array(t1); L_vAA = upload_array(t2); L_dg = upload_array(t3);
+        up.reset();
+        HIPC(hipStreamSynchronize(st));
+        if (dot_parts(Lm) + 64 > part_uc_cap) {                                                     // partials of dot(u, mL u): one per workgroup of the product's last launch
+            (void)hipFree(part_uc);
+            part_uc_cap = dot_parts(Lm) + 64; part_uc = dalloc<double>(part_uc_cap, st);
+        }
+        explicit_state = 1; L_valid = false;
+        return true;
+    }
+    // the values of mL for (rho, sigma): LinearSystemSolvers.jl:114 at Init, :127-129 on changedRho -- elementwise on the frozen pattern, then the column-blocked copy refreshed
+    void reduced_values(double rho, double sigma) {
+        if (L_valid && L_rho == rho && L_sigma == sigma) return;
+        const int64_t nnz = Lm.nnz;
+        if (nnz > 0) hipLaunchKernelGGL((k_build_reduced<T>), dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, L_vP, L_vAA, L_dg, (T)sigma, (T)rho, static_cast<T*>(Lm.va));
+        if (Lm.blocked) {
+            T* main_vals = static_cast<T*>(Lm.sell ? Lm.s_vals : Lm.bva);
+            if (Lm.src_n > 0) hipLaunchKernelGGL((k_refresh_values<T>), dim3((unsigned)((Lm.src_n + 255) / 256)), dim3(256), 0, st, Lm.src_n, Lm.src, static_cast<const T*>(Lm.va), main_vals);
+            if (Lm.sell && Lm.lsrc_n > 0)
+                hipLaunchKernelGGL((k_refresh_values<T>), dim3((unsigned)((Lm.lsrc_n + 255) / 256)), dim3(256), 0, st, Lm.lsrc_n, Lm.lsrc, static_cast<const T*>(Lm.va), static_cast<T*>(Lm.bva));
+        }
+        L_valid = true; L_rho = rho; L_sigma = sigma; ++num_L_builds;
     }
     // Which plugin a request means on a CSC handle, with the direct one factorised.  QPS_LINSYS_AUTO is the reference's modeAuto rule
     // (SolveQuadraticProgram.jl:143-151, qps_linsys_auto) on this handle's sizes and non-zero counts, so that a C caller passing AUTO reaches the direct
     // KKT plugin exactly when the reference would; when the factor then does not fit the level-scheduled plugin (QPS_ERR_UNSUPPORTED from the analysis) an
     // AUTO request falls back to CG -- an EXPLICIT QPS_LINSYS_KKT_LDL request still fails loudly.
+    // A CG request is served by the explicit reduced matrix (ItrSolCg, one product per CG iteration) when the handle has one -- always for
+    // QPS_LINSYS_CG_EXPLICIT, for QPS_LINSYS_CG / AUTO when explicit_prepare finds that it pays (QPS_CG_EXPLICIT = 0 keeps those matrix-free) -- else by the
+    // matrix-free operator (LinOpCg / LinMapsCg, three products).
+    int resolve_cg(int linsys, double rho, double sigma) {
+        const char* e = getenv("QPS_CG_EXPLICIT");                                                  // read per request
+        cg_explicit = linsys == QPS_LINSYS_CG_EXPLICIT ? explicit_prepare(true) : (!(e && atoi(e) == 0) && explicit_prepare(false));
+        if (cg_explicit) reduced_values(rho, sigma);
+        return QPS_LINSYS_CG;
+    }
     int resolve_kind(int linsys, double rho, double sigma, bool force) {
         int kind = linsys;
         if (linsys == QPS_LINSYS_AUTO) kind = qps_linsys_auto(n, m, P.nnz, A.nnz, 1);
-        if (kind != QPS_LINSYS_KKT_LDL) return QPS_LINSYS_CG;
-        if (ldl_unfit && linsys == QPS_LINSYS_AUTO) return QPS_LINSYS_CG;
+        if (kind != QPS_LINSYS_KKT_LDL) return resolve_cg(linsys, rho, sigma);
+        if (ldl_unfit && linsys == QPS_LINSYS_AUTO) return resolve_cg(linsys, rho, sigma);
         try { ldl_prepare(rho, sigma, force); }
         catch (const QpsError& e) {
-            if (linsys == QPS_LINSYS_AUTO && e.code == QPS_ERR_UNSUPPORTED) { ldl_unfit = true; return QPS_LINSYS_CG; }
+            if (linsys == QPS_LINSYS_AUTO && e.code == QPS_ERR_UNSUPPORTED) { ldl_unfit = true; return resolve_cg(linsys, rho, sigma); }
             throw;
         }
         return QPS_LINSYS_KKT_LDL;
@@ -985,7 +894,7 @@ template <typename T> struct SparseSolver : SolverBase {
             ldl = make_sparse_ldl<T>(st, std::move(sym), hPnz.data(), (int64_t)hPnz.size(), hAnz.data(), (int64_t)hAnz.size());
             ldl_valid = false;
             for (auto* v : {&hPcp, &hPri, &hAcp, &hAri}) std::vector<int64_t>().swap(*v);           // the canonical host copies have served their purpose
-            std::vector<double>().swap(hPnz); std::vector<double>().swap(hAnz);
+            std::vector<double>().swap(hPnz); std::vector<double>().swap(hAnz);                     // (a later CG request stays matrix-free: explicit_prepare)
         }
         if (force || !ldl_valid || ldl_rho != rho || ldl_sigma != sigma) {
             ldl_valid = false;
@@ -1003,35 +912,25 @@ template <typename T> struct SparseSolver : SolverBase {
         st = res.st;
         prof.st = st;
         up.reset(new StagedUploader(st));
-        const int64_t pnnz = Pcp[n] - base, annz = Acp[n] - base;
-        if (pnnz > 2000000000LL || annz > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 non-zeros");
-        // P: CSC == CSR (symmetric, full storage).  A': rows of A' are the columns of A == the caller's CSC.
-        std::vector<int> prp(n + 1), pci(pnnz), atrp(n + 1), atci(annz), arp(m + 1, 0), aci(annz);
-        std::vector<double> pva(Pnz, Pnz + pnnz), atva(Anz, Anz + annz), ava(annz);
-        for (int64_t j = 0; j <= n; ++j) { prp[j] = (int)(Pcp[j] - base); atrp[j] = (int)(Acp[j] - base); }
-        for (int64_t k = 0; k < pnnz; ++k) pci[k] = (int)(Pri[k] - base);
-        for (int64_t k = 0; k < annz; ++k) { atci[k] = (int)(Ari[k] - base); arp[atci[k] + 1]++; }
-        for (int64_t i = 0; i < m; ++i) arp[i + 1] += arp[i];
-        {   // rows of A by a counting sort over the CSC (columns visited in order -> sorted column indices per row)
-            std::vector<int> pos(arp.begin(), arp.end() - 1);
-            for (int64_t j = 0; j < n; ++j)
-                for (int k = atrp[j]; k < atrp[j + 1]; ++k) { const int r = atci[k]; aci[pos[r]] = (int)j; ava[pos[r]] = atva[k]; pos[r]++; }
-        }
-        canonical_csc((int)n, Pcp, Pri, Pnz, base, hPcp, hPri, hPnz);     // sorted rows, duplicates summed, 0-based: input of the LDL' plugin
-        canonical_csc((int)n, Acp, Ari, Anz, base, hAcp, hAri, hAnz);
-        upload_csr(P, (int)n, (int)n, prp, pci, pva);
-        upload_csr(At, (int)n, (int)m, atrp, atci, atva);
-        upload_csr(A, (int)m, (int)n, arp, aci, ava);
+        if (Pcp[n] - base > 2000000000LL || Acp[n] - base > 2000000000LL) throw QpsError(QPS_ERR_BAD_DIMENSION, "more than 2^31 non-zeros");
+        // canonical host copies first (sorted rows, duplicates summed, 0-based: a C caller's CSC need not be what Julia's sparse() guarantees);
+        // they feed the CSR copies below and, later, the analysis of the L D L' plugin
+        layout::canonical_csc(n, Pcp, Pri, Pnz, base, hPcp, hPri, hPnz);
+        layout::canonical_csc(n, Acp, Ari, Anz, base, hAcp, hAri, hAnz);
+        const int64_t pnnz = (int64_t)hPri.size(), annz = (int64_t)hAri.size();
+        layout::CsrHost Ph, Ah, Ath;
+        try {
+            Ph = layout::csc_as_transposed_csr(n, n, hPcp, hPri, hPnz);      // P: CSC == CSR (symmetric, full storage): its columns are its rows
+            layout::csc_to_csr_pair(m, n, hAcp, hAri, hAnz, Ah, Ath);        // rows of A by a counting sort; rows of A' are the columns of A == the CSC
+        } catch (const std::length_error& ex) { throw QpsError(QPS_ERR_BAD_DIMENSION, ex.what()); }
+        upload_csr(P, Ph);
+        upload_csr(At, Ath);
+        upload_csr(A, Ah);
         const char* fuse_env = getenv("QPS_SPMV_FUSEPA");                 // 0: keep P, A, A' as three separate blocked products
         if (m > 0 && P.blocked && A.blocked && At.blocked && pnnz + annz < 2000000000LL && !(fuse_env && atoi(fuse_env) == 0)) {
-            std::vector<int> srp((size_t)(n + m + 1)), sci; std::vector<double> sva;
-            sci.reserve((size_t)(pnnz + annz)); sva.reserve((size_t)(pnnz + annz));
-            sci.insert(sci.end(), pci.begin(), pci.end()); sci.insert(sci.end(), aci.begin(), aci.end());
-            sva.insert(sva.end(), pva.begin(), pva.end()); sva.insert(sva.end(), ava.begin(), ava.end());
-            for (int64_t i = 0; i <= n; ++i) srp[i] = prp[i];
-            for (int64_t i = 1; i <= m; ++i) srp[n + i] = (int)pnnz + arp[i];
+            const layout::CsrHost Sh = layout::stack_rows(Ph, Ah);
             PA.nrows = (int)(n + m); PA.nnz = pnnz + annz;
-            build_blocked(PA, (int)n, srp, sci, sva);
+            build_blocked(PA, Sh);
         }
         const int64_t nn = n + 64, mm = m + 64;
         q = dalloc<T>(nn, st); x = dalloc<T>(nn, st); xp = dalloc<T>(nn, st); xx = dalloc<T>(nn, st); tt = dalloc<T>(nn, st);
@@ -1039,7 +938,8 @@ template <typename T> struct SparseSolver : SolverBase {
         l = dalloc<T>(mm, st); u = dalloc<T>(mm, st); z = dalloc<T>(mm, st); zp = dalloc<T>(mm, st); y = dalloc<T>(mm, st); zz = dalloc<T>(mm, st);
         w = dalloc<T>(mm, st); tm = dalloc<T>(mm, st); Ax = dalloc<T>(mm, st);
         nb_n = (int)((n + 255) / 256);
-        part_uc = dalloc<double>(std::max(std::max(At.nblocks, P.nblocks), nb_n + (int)((m + 255) / 256)) + 64, st); part_rr = dalloc<double>(nb_n + 64, st);
+        part_uc_cap = std::max(std::max(At.nblocks, P.nblocks), nb_n + (int)((m + 255) / 256)) + 64;
+        part_uc = dalloc<double>(part_uc_cap, st); part_rr = dalloc<double>(nb_n + 64, st);
         state = reinterpret_cast<CgState*>(dalloc<double>(16, st));
         state_host = reinterpret_cast<CgState*>(res.pinned);                          // pinned block: CG state | check results
         scratch = dalloc<unsigned long long>(16, st); res_dev = dalloc<double>(16, st);
@@ -1064,10 +964,11 @@ template <typename T> struct SparseSolver : SolverBase {
         if (st) (void)hipStreamSynchronize(st);
         drop_graphs();
         if (cu2) (void)hipFree(cu2);
-        for (Csr* M_ : {&A, &At, &P, &PA}) {
-            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial, M_->lr_ptr, M_->lr_desc, M_->wg_ptr, M_->sl_off, M_->sl_perm, M_->s_cols, M_->s_vals};
+        for (Csr* M_ : {&A, &At, &P, &PA, &Lm}) {
+            void* bp[] = {M_->brp, M_->bci, M_->bva, M_->task_ptr, M_->tasks, M_->partial, M_->lr_ptr, M_->lr_desc, M_->wg_ptr, M_->sl_off, M_->sl_perm, M_->s_cols, M_->s_vals, M_->src, M_->lsrc};
             for (void* p : bp) if (p) (void)hipFree(p);
         }
+        { void* lp[] = {Lm.rp, Lm.ci, Lm.va, Lm.rb, L_vP, L_vAA, L_dg}; for (void* p : lp) if (p) (void)hipFree(p); }
         void* ptrs[] = {A.rp, A.ci, A.va, A.rb, At.rp, At.ci, At.va, At.rb, P.rp, P.ci, P.va, P.rb, q, l, u, x, xp, z, zp, y, xx, zz, w, tt, cu, cr, cc, tm,
                         Ax, Px, Aty, part_uc, part_rr, state, scratch, res_dev, stage};
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1135,17 +1036,29 @@ template <typename T> struct SparseSolver : SolverBase {
     int cg(double rho, double sigma) {
         CgState* slot[2] = {state, state + 1};
         int cur = 0;
-        op_reduced(xx, cc, rho, sigma, nullptr, nullptr);
+        // c = mL u: ONE product with the explicit matrix (ItrSolCg!, LinearSystemSolvers.jl:137) or the three of the matrix-free operator (:152-157)
+        auto apply_op = [&](const T* uin, T* cout, double* partial, const CgState* stt) {
+            if (cg_explicit) spmv(Lm, uin, cout, T(1), nullptr, T(0), nullptr, T(0), stt, partial ? uin : nullptr, partial);
+            else op_reduced(uin, cout, rho, sigma, partial, stt);
+        };
+        const int parts_op = cg_explicit ? dot_parts(Lm) : op_parts();
+        const bool fused_pa = PA.blocked && !cg_explicit;
+        apply_op(xx, cc, nullptr, nullptr);
         T* ub[2] = {cu, cu2}; int ui = 0;                            // ub[ui] = current direction u
         hipLaunchKernelGGL((k_cg_init<T>), dim3(nb_n), dim3(256), 0, st, (int)n, tt, cc, cr, ub[ui], part_rr);
         hipLaunchKernelGGL(k_cg_init_final, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur], eps_pcg,
                            sizeof(T) == 8 ? 1.4901161193847656e-08 : 3.4526698300124393e-04, itr_pcg);
-        int launched = 0, batch = std::max(1, std::min(last_cg + 1, 64));
+        // Launch batches: the first one is the previous call's iteration count (consecutive ADMM iterations need nearly the same number); every further
+        // one is what the measured contraction says is left (res_end / res_init over the iterations run so far), at least one and never more than doubles
+        // the total.  An iteration enqueued past convergence still costs four dispatches that return at the done flag: with "last + 1, then double" a
+        // sixth of the product dispatches of BASELINE config 3 were such no-ops (profiles/r03_z_bench_c3_kernel_stats.csv).
+        HIPC(hipMemcpyAsync(state_host + 1, slot[cur], sizeof(CgState), hipMemcpyDeviceToHost, st));   // the initial residual, read at the first synchronisation
+        int launched = 0, batch = std::max(1, std::min(last_cg, 64));
         for (;;) {
             for (int b = 0; b < batch; ++b) {
                 ProfScope ps(prof, cat_op, 2);
                 // fold the previous iteration's ||r||^2, publish the scalars into the other slot, u = r + beta u
-                if (PA.blocked) {
+                if (fused_pa) {
                     // [P; A] u with u = r + beta u_old formed while the x blocks are loaded; then A'(A u); ONE combine for c and dot(u, c)
                     CgFuse<T> fu; fu.r = cr; fu.uold = ub[ui]; fu.unew = ub[ui ^ 1]; fu.part_rr = part_rr; fu.nparts = nb_n;
                     fu.cur = slot[cur]; fu.nxt = slot[cur ^ 1]; fu.first = b == 0 ? 1 : 0;
@@ -1164,9 +1077,9 @@ template <typename T> struct SparseSolver : SolverBase {
                 } else {
                     hipLaunchKernelGGL((k_cg_next_u<T>), dim3(nb_n), dim3(256), 0, st, (int)n, nb_n, part_rr, cr, ub[ui], slot[cur], slot[cur ^ 1], b == 0 ? 1 : 0);
                     cur ^= 1;
-                    op_reduced(ub[ui], cc, rho, sigma, part_uc, slot[cur]);
+                    apply_op(ub[ui], cc, part_uc, slot[cur]);
                 }
-                hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, PA.blocked ? nb_n : op_parts(), part_uc, ub[ui], cc, xx, cr, part_rr, slot[cur]);
+                hipLaunchKernelGGL((k_cg_update_xr<T>), dim3(nb_n), dim3(256), 0, st, (int)n, parts_op, part_uc, ub[ui], cc, xx, cr, part_rr, slot[cur]);
             }
             hipLaunchKernelGGL(k_cg_finish, dim3(1), dim3(256), 0, st, nb_n, part_rr, slot[cur]);   // fold the last iteration of the batch
             launched += batch;
@@ -1174,7 +1087,15 @@ template <typename T> struct SparseSolver : SolverBase {
             HIPC(hipStreamSynchronize(st));
             prof.harvest();
             if (state_host->done || launched >= itr_pcg) break;
-            batch = std::min(std::max(batch, 4) * 2, 64);
+            {
+                const double r0 = std::sqrt(state_host[1].res2), r1 = std::sqrt(state_host->res2), tol = state_host->tol;
+                int left = std::max(launched, 1);                                                   // no usable rate: as many again
+                if (r1 > 0 && r0 > r1 && tol > 0 && r1 > tol) {
+                    const double per_it = std::log(r0 / r1) / std::max(1, state_host->iters);       // contraction per iteration so far
+                    left = (int)std::ceil(std::log(r1 / tol) / per_it);
+                }
+                batch = std::max(1, std::min(std::min(std::max(left, 2), std::max(launched, 2)), std::min(64, itr_pcg - launched)));   // (two at least: a synchronisation costs about one iteration)
+            }
         }
         last_cg = state_host->iters;
         ++prof_calls;
@@ -1209,7 +1130,7 @@ template <typename T> struct SparseSolver : SolverBase {
         eps_pcg = p.epsPcg; itr_pcg = p.numItrPcg;
         const double epsAdmm = std::fmin(p.epsAbs, p.epsRel) * 1e-2;
         int convFlag = QPS_CONV_NUM_ITR;
-        if (p.linsys == QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
+        if (p.linsys == QPS_LINSYS_CHOLESKY) throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG, QPS_LINSYS_CG_EXPLICIT and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
         plugin_kind = resolve_kind(p.linsys, rho, sigma, !p.reuseFactor);                           // SolveQuadraticProgram.jl:36 LinSysSolInit (incl. the factorisation)
         upload_vec(xh, x, n);
         const size_t nb_ = sizeof(T) * (size_t)(n + 64), mb_ = sizeof(T) * (size_t)(m + 64);
@@ -1225,7 +1146,8 @@ template <typename T> struct SparseSolver : SolverBase {
         bool ldl_rhs_ready = false;   // the fused post/update launch leaves the next right-hand side behind; stale after a rho switch
         for (ii = 1; ii <= p.numIterations; ++ii) {
             if (p.adptRho && ((rhorho * p.fctrRho < rho) || (rhorho > p.fctrRho * rho))) {
-                rho = rhorho; ++nref;                                                               // CG: the operator is matrix-free, nothing to rebuild
+                rho = rhorho; ++nref;                                                               // matrix-free CG: nothing to rebuild
+                if (plugin_kind == QPS_LINSYS_CG && cg_explicit) { const double ta = now_s(); reduced_values(rho, sigma); tref += now_s() - ta; }   // changedΡ: LinearSystemSolvers.jl:127-129
                 if (plugin_kind == QPS_LINSYS_KKT_LDL) { const double ta = now_s(); ldl_prepare(rho, sigma, true); tref += now_s() - ta; ldl_rhs_ready = false; }   // changedΡ: numeric refactor only
             }
             if (plugin_kind == QPS_LINSYS_KKT_LDL && prof.level < 2) {
@@ -1270,7 +1192,7 @@ template <typename T> struct SparseSolver : SolverBase {
             info->convFlag = convFlag; info->iterations = ii > p.numIterations ? p.numIterations : ii;
             info->numRefactor = nref; info->cgIterations = (int)cg_total; info->rhoFinal = rho; info->rhoProposed = rhorho;
             info->resPrim = resP; info->resDual = resD; info->tSetup = t1 - t0; info->tLoop = t2 - t1; info->tRefactor = tref;
-            info->trsvBlock = 0; info->sweepVariant = 0; info->sweepGaveUp = 0; info->reserved1 = 0;
+            info->trsvBlock = 0; info->sweepVariant = 0; info->sweepGaveUp = 0; info->cgExplicit = (plugin_kind == QPS_LINSYS_CG && cg_explicit) ? 1 : 0;
             info->polishFlag = pr.flag; info->polishIterations = pr.minresIterations; info->tPolish = pr.seconds;
         }
     }
@@ -1301,11 +1223,40 @@ template <typename T> struct SparseSolver : SolverBase {
             rep->numActiveLower = pr.numLower; rep->numActiveUpper = pr.numUpper; rep->reserved0 = 0; rep->relres = pr.relres; rep->seconds = pr.seconds;
         }
     }
+    // qps_operator_apply: one application of P / A / A' / [P; A] / the reduced operator (LinearSystemSolvers.jl:152-157) through the SpMV kernels the loop
+    // uses for them; work buffers only (cu, cc: n; w, tm: m), the solver state stays
+    void operator_apply(int op, const double* in, double* out, double rho, double sigma) override {
+        HIPC(hipSetDevice(device));
+        if (op == QPS_OP_AT) {
+            upload_vec(in, w, m);
+            if (m > 0) spmv(At, w, cc, T(1), nullptr, T(0), nullptr, T(0), nullptr); else HIPC(hipMemsetAsync(cc, 0, sizeof(T) * (size_t)(n + 64), st));
+            download_vec(cc, out, n);
+            return;
+        }
+        upload_vec(in, cu, n);
+        if (op == QPS_OP_P) { spmv(P, cu, cc, T(1), nullptr, T(0), nullptr, T(0), nullptr); download_vec(cc, out, n); }
+        else if (op == QPS_OP_A) { if (m > 0) spmv(A, cu, tm, T(1), nullptr, T(0), nullptr, T(0), nullptr); download_vec(tm, out, m); }
+        else if (op == QPS_OP_PA) {
+            if (PA.blocked) {                                                                       // the stacked product of a CG iteration, then its blocks added up
+                spmv_blk(PA, cu, nullptr);
+                T* both = dalloc<T>(n + m + 64, st);
+                hipLaunchKernelGGL((k_spmv_combine<T>), dim3((unsigned)((n + m + 255) / 256)), dim3(256), 0, st, (int)(n + m), static_cast<const T*>(PA.partial), PA.nblk, (int64_t)(n + m),
+                                   T(1), (const T*)nullptr, 0, (int64_t)0, T(0), (const T*)nullptr, T(0), (const T*)nullptr, T(0), both, (const T*)nullptr, (double*)nullptr, (const CgState*)nullptr);
+                download_vec(both, out, n); download_vec(both + n, out + n, m);
+                (void)hipFree(both);
+            } else {
+                spmv(P, cu, cc, T(1), nullptr, T(0), nullptr, T(0), nullptr); download_vec(cc, out, n);
+                if (m > 0) spmv(A, cu, tm, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                download_vec(tm, out + n, m);
+            }
+        } else if (op == QPS_OP_REDUCED) { op_reduced(cu, cc, rho, sigma, nullptr, nullptr); download_vec(cc, out, n); }
+        else throw QpsError(QPS_ERR_BAD_ARGUMENT, "unknown qps_operator_kind");
+    }
     void linsys_set_cg(double eps, int itr) override { eps_pcg = eps; itr_pcg = itr; }             // LinOpCg!(...; ϵPcg, numItrPcg): LinearSystemSolvers.jl:164
     void linsys_init(double rho, double sigma, int linsys, int) override {
         HIPC(hipSetDevice(device));
-        if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG && linsys != QPS_LINSYS_KKT_LDL)
-            throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
+        if (linsys != QPS_LINSYS_AUTO && linsys != QPS_LINSYS_CG && linsys != QPS_LINSYS_KKT_LDL && linsys != QPS_LINSYS_CG_EXPLICIT)
+            throw QpsError(QPS_ERR_UNSUPPORTED, "CSR handles offer QPS_LINSYS_CG, QPS_LINSYS_CG_EXPLICIT and QPS_LINSYS_KKT_LDL (create with dense_path=1 for the reduced Cholesky path)");
         plugin_kind = resolve_kind(linsys, rho, sigma, true);                                       // LinearSystemSolvers.jl:18 / :49 / :81
         if (plugin_kind == QPS_LINSYS_KKT_LDL) return;
         HIPC(hipMemsetAsync(xx, 0, sizeof(T) * (size_t)(n + 64), st));                              // LinOpCgInit (:147)
@@ -1317,6 +1268,7 @@ template <typename T> struct SparseSolver : SolverBase {
             if (!ldl) throw QpsError(QPS_ERR_BAD_ARGUMENT, "qps_linsys_solve called before qps_linsys_init");
             if (changed) ldl_prepare(rho, sigma, true);                                             // :30-32 / :61-63 / :93-95
         }
+        if (plugin_kind == QPS_LINSYS_CG && cg_explicit) reduced_values(rho, sigma);                 // :127-129 (a no-op while rho and sigma are the cached ones)
         upload_vec(xh, x, n); upload_vec(zh, z, m); upload_vec(yh, y, m);
         linear_solve(rho, sigma);
         HIPC(hipStreamSynchronize(st));
@@ -1379,8 +1331,8 @@ template <typename T> struct SparseProxQpSolver : ProxQpBase {
         slots = dalloc<unsigned long long>(16, st);
         slots_host = reinterpret_cast<unsigned long long*>(ss->res.pinned);
         ss->upload_vec(gh.data(), g, mtot);
-        SparseSolver<T>::canonical_csc((int)n, P0cp.data(), P0ri.empty() ? dummy_i : P0ri.data(), Pnz, 0, kPcp, kPri, kPnz);
-        if (me > 0) SparseSolver<T>::canonical_csc((int)n, Acp, Ari, Anz, base, kAcp, kAri, kAnz);
+        layout::canonical_csc(n, P0cp.data(), P0ri.empty() ? dummy_i : P0ri.data(), Pnz, 0, kPcp, kPri, kPnz);
+        if (me > 0) layout::canonical_csc(n, Acp, Ari, Anz, base, kAcp, kAri, kAnz);
         else kAcp.assign(n + 1, 0);
     }
     ~SparseProxQpSolver() override {

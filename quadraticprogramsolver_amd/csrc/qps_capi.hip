@@ -5,6 +5,7 @@
 // There is NO CPU fallback: without a HIP device every entry point fails with QPS_ERR_NO_DEVICE.
 #include "ldl_symbolic.h"
 #include "qps_internal.h"
+#include "spmv_layout.h"
 #include "qps_kernels.h"
 #include "qps_polish.h"
 #include "qps_proxqp.h"
@@ -337,7 +338,7 @@ template <typename T> struct DenseSolver : SolverBase {
             ++gave_up; t_lost = now_s() - t_begin;
             const int lvl = prof.level; prof.reset(); prof.level = lvl;   // the aborted attempt's launches are not this solve's kernels
         }
-        if (info) { info->sweepGaveUp = gave_up; info->reserved1 = 0; info->tLoop += t_lost; }   // the repeated work is loop time
+        if (info) { info->sweepGaveUp = gave_up; info->cgExplicit = 0; info->tLoop += t_lost; }   // the repeated work is loop time
     }
     bool solve_once(double* xh, const qps_params& p, qps_info* info) {
         if (p.linsys != QPS_LINSYS_AUTO && p.linsys != QPS_LINSYS_CHOLESKY)
@@ -526,6 +527,27 @@ template <typename T> struct DenseSolver : SolverBase {
         linear_solve(rho, sigma);
         if (sweep_gave_up()) { factorize(rho, sigma, false); linear_solve(rho, sigma); }
         download_vec(xx, xxh, n); download_vec(zz, zzh, m);
+    }
+    // qps_operator_apply: the GEMVs the loop and CheckConvergence use (SolveQuadraticProgram.jl:85-89), on work buffers only (x, z, y stay)
+    void operator_apply(int op, const double* in, double* out, double rho, double sigma) override {
+        HIPC(hipSetDevice(device));
+        auto Pin = [&](T* dst) { gemv_rows<T>(st, P, NP, xx, dst, nullptr, T(1), T(0), 0, NP, 0, NP, 0); };
+        auto Ain = [&](T* dst) { if (m > 0) gemv_rows<T>(st, A, NP, xx, dst, nullptr, T(1), T(0), 0, MP, 0, NP, 0); };
+        auto Atv = [&](const T* v, T* dst) {
+            if (m > 0) { gemv_cols_partial<T>(st, A, NP, v, nullptr, T(1), T(0), part, NP, MP, NP); colsum<T>(st, part, NP, part_tiles, nullptr, T(0), nullptr, T(0), dst, NP); }
+            else HIPC(hipMemsetAsync(dst, 0, sizeof(T) * NP, st));
+        };
+        if (op == QPS_OP_AT) { upload_vec(in, zz, m); Atv(zz, Aty); download_vec(Aty, out, n); return; }
+        upload_vec(in, xx, n);
+        if (op == QPS_OP_P) { Pin(Px); download_vec(Px, out, n); }
+        else if (op == QPS_OP_A) { Ain(Ax); download_vec(Ax, out, m); }
+        else if (op == QPS_OP_PA) { Pin(Px); Ain(Ax); download_vec(Px, out, n); download_vec(Ax, out + n, m); }
+        else if (op == QPS_OP_REDUCED) {                                                            // LinearSystemSolvers.jl:152-157
+            Pin(Px); Ain(Ax); Atv(Ax, Aty);
+            std::vector<double> a((size_t)n), b((size_t)n);
+            download_vec(Px, a.data(), n); download_vec(Aty, b.data(), n);
+            for (int64_t i = 0; i < n; ++i) out[i] = a[(size_t)i] + rho * b[(size_t)i] + sigma * in[i];
+        } else throw QpsError(QPS_ERR_BAD_ARGUMENT, "unknown qps_operator_kind");
     }
 };
 
@@ -837,7 +859,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
                 in.tSetup = t1 - t0; in.tLoop = t2 - t1; in.tRefactor = tref[b];   // wall time of the whole batch
                 in.polishFlag = pol[b].flag; in.polishIterations = pol[b].minresIterations; in.tPolish = pol[b].seconds;
                 in.trsvBlock = nb; in.sweepVariant = (nblk == 1 && sweep_fused_supported<T>(NP)) ? 2 : (nblk == 1 ? 3 : 1);
-                in.sweepGaveUp = 0; in.reserved1 = 0;
+                in.sweepGaveUp = 0; in.cgExplicit = 0;
             }
         }
     }
@@ -872,45 +894,6 @@ int64_t dense_asymmetry(const double* P, int64_t n, int64_t ldp) {
                 for (int64_t i = std::max(i0, j + 1); i < i1; ++i)
                     if (P[i + j * ldp] != P[j + i * ldp]) return j;
         }
-    return -1;
-}
-// Same test on a CSC matrix: columns sorted by row with duplicates summed (what Julia's sparse() guarantees; C callers may not),
-// then compared entry by entry with the transpose built by a counting sort.
-int64_t csc_asymmetry(int64_t n, const int64_t* cp, const int64_t* ri, const double* nz, int base) {
-    const int64_t nnz = cp[n] - base;
-    std::vector<int64_t> scp(n + 1, 0), sri; std::vector<double> snz;
-    sri.reserve((size_t)nnz); snz.reserve((size_t)nnz);
-    std::vector<std::pair<int64_t, double>> col;
-    for (int64_t j = 0; j < n; ++j) {
-        col.clear();
-        for (int64_t k = cp[j] - base; k < cp[j + 1] - base; ++k) col.emplace_back(ri[k] - base, nz[k]);
-        if (!std::is_sorted(col.begin(), col.end(), [](const auto& a, const auto& b) { return a.first < b.first; }))
-            std::stable_sort(col.begin(), col.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-        for (size_t k = 0; k < col.size(); ++k) {
-            if (!sri.empty() && (int64_t)sri.size() > scp[j] && sri.back() == col[k].first) snz.back() += col[k].second;
-            else { sri.push_back(col[k].first); snz.push_back(col[k].second); }
-        }
-        scp[j + 1] = (int64_t)sri.size();
-    }
-    const int64_t snnz = (int64_t)sri.size();
-    std::vector<int64_t> tcp(n + 1, 0), tri((size_t)snnz); std::vector<double> tnz((size_t)snnz);
-    for (int64_t k = 0; k < snnz; ++k) tcp[sri[k] + 1]++;
-    for (int64_t i = 0; i < n; ++i) tcp[i + 1] += tcp[i];
-    {
-        std::vector<int64_t> pos(tcp.begin(), tcp.end() - 1);
-        for (int64_t j = 0; j < n; ++j)
-            for (int64_t k = scp[j]; k < scp[j + 1]; ++k) { const int64_t r = sri[k]; tri[pos[r]] = j; tnz[pos[r]] = snz[k]; pos[r]++; }
-    }
-    // explicit zeros on one side only are still symmetric values: compare through a merge that treats a missing entry as 0
-    for (int64_t j = 0; j < n; ++j) {
-        int64_t a = scp[j], b = tcp[j];
-        while (a < scp[j + 1] || b < tcp[j + 1]) {
-            const int64_t ra = a < scp[j + 1] ? sri[a] : n, rb = b < tcp[j + 1] ? tri[b] : n;
-            if (ra == rb) { if (snz[a] != tnz[b]) return j; ++a; ++b; }
-            else if (ra < rb) { if (snz[a] != 0.0) return j; ++a; }
-            else { if (tnz[b] != 0.0) return j; ++b; }
-        }
-    }
     return -1;
 }
 int check_device(int device) {
@@ -1021,16 +1004,17 @@ QPS_API int32_t qps_create_csc(int64_t n, int64_t m, const int64_t* Pcp, const i
     if (!Pcp || !q || !Acp || (m > 0 && (!l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
     if (index_base != 0 && index_base != 1) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "index_base must be 0 or 1");
     if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
-    const int64_t pnnz = Pcp[n] - index_base, annz = Acp[n] - index_base;
-    if (Pcp[0] != index_base || Acp[0] != index_base || pnnz < 0 || annz < 0) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr does not start at index_base");
-    for (int64_t j = 0; j < n; ++j) if (Pcp[j + 1] < Pcp[j] || Acp[j + 1] < Acp[j]) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "colptr not monotone");
-    for (int64_t k = 0; k < pnnz; ++k) if (Pri[k] - index_base < 0 || Pri[k] - index_base >= n) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "P row index out of range");
-    for (int64_t k = 0; k < annz; ++k) if (Ari[k] - index_base < 0 || Ari[k] - index_base >= m) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "A row index out of range");
-    if (!all_finite(Pnz, pnnz, false) || !all_finite(Anz, annz, false) || !all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P/A/q contain NaN/Inf");
+    {   // colptr / rowval / nzval of both matrices (plain host code shared with the CPU tests: spmv_layout.cpp)
+        std::string why;
+        int vc = layout::validate_csc(n, n, Pcp, Pri, Pnz, index_base, "P", &why);
+        if (vc == 0) vc = layout::validate_csc(m, n, Acp, Ari, Anz, index_base, "A", &why);
+        if (vc != 0) return fail_with(nullptr, vc, why);
+    }
+    if (!all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "q contains NaN/Inf");
     if (m > 0 && (!all_finite(l, m, true) || !all_finite(u, m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
     {
         int64_t bad = -1;
-        int src = guarded(nullptr, [&] { bad = csc_asymmetry(n, Pcp, Pri, Pnz, index_base); });   // SolveQuadraticProgram.m:166-168
+        int src = guarded(nullptr, [&] { bad = layout::csc_asymmetry(n, Pcp, Pri, Pnz, index_base); });   // SolveQuadraticProgram.m:166-168
         if (src != QPS_OK) return src;
         if (bad >= 0) { char b[160]; snprintf(b, sizeof b, "The matrix mP must be a symmetric positive definite matrix (asymmetric entry in column %lld)", (long long)bad); return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, b); }
     }
@@ -1101,6 +1085,16 @@ QPS_API int32_t qps_linsys_solve(qps_handle hh, const double* x, const double* z
     if (!x || !xx || (h->m > 0 && (!z || !y || !zz))) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "NULL vector");
     if (!(rho > 0) || !(sigma >= 0)) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "rho must be positive, sigma non-negative");
     return guarded(h, [&] { h->impl->linsys_solve(x, z, y, rho, sigma, changed, xx, zz); });
+}
+
+QPS_API int32_t qps_operator_apply(qps_handle hh, int32_t op, const double* in, double* out, double rho, double sigma) {
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!h || !h->impl) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "invalid handle (qps_operator_apply takes a single-problem handle)");
+    if (op < QPS_OP_P || op > QPS_OP_REDUCED) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "unknown qps_operator_kind");
+    if (!in || !out) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "NULL vector");
+    if (op == QPS_OP_REDUCED && (!(rho >= 0) || !(sigma >= 0))) return fail_with(h, QPS_ERR_BAD_ARGUMENT, "rho and sigma must be non-negative");
+    if (!all_finite(in, op == QPS_OP_AT ? h->m : h->n, false)) return fail_with(h, QPS_ERR_NOT_FINITE, "the input vector contains NaN/Inf");
+    return guarded(h, [&] { h->impl->operator_apply(op, in, out, rho, sigma); });
 }
 
 QPS_API int32_t qps_linsys_set_cg(qps_handle hh, double epsPcg, int32_t numItrPcg) {

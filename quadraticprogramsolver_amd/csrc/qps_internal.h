@@ -164,6 +164,9 @@ struct SolverBase {
     virtual void linsys_set_cg(double eps_pcg, int num_itr_pcg) { (void)eps_pcg; (void)num_itr_pcg; }   // direct plugins: no inner iteration
     virtual void linsys_solve(const double* x, const double* z, const double* y, double rho, double sigma, int changed,
                               double* xx, double* zz) = 0;
+    virtual void operator_apply(int op, const double* in, double* out, double rho, double sigma) {   // qps_operator_apply
+        (void)op; (void)in; (void)out; (void)rho; (void)sigma; throw QpsError(QPS_ERR_UNSUPPORTED, "qps_operator_apply is not implemented for this handle type");
+    }
 };
 
 

@@ -23,7 +23,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import QPS_F32, QPS_F64, QPS_LINSYS_AUTO, QPS_LINSYS_CG, QPS_LINSYS_CHOLESKY, QPS_LINSYS_KKT_LDL, QpsInfo
+from ._lib import QPS_F32, QPS_F64, QPS_LINSYS_AUTO, QPS_LINSYS_CG, QPS_LINSYS_CG_EXPLICIT, QPS_LINSYS_CHOLESKY, QPS_LINSYS_KKT_LDL, QpsInfo
 
 
 class LinearSolverMode(enum.IntEnum):
@@ -73,8 +73,9 @@ def _validate_dims(numElementsX, mP, vQ, mA, vL, vU):
 class QuadraticProgram:
     """A problem resident in HBM (qps_create_dense / qps_create_csc ... qps_destroy).
 
-    ``linsys``: "cholesky" (dense reduced form; sparse inputs are densified on the device), "cg" (CSR, matrix-free CG on the
-    reduced operator) or "ldl" (CSR, sparse L D L' of the KKT matrix: the reference's direct plugins).
+    ``linsys``: "cholesky" (dense reduced form; sparse inputs are densified on the device), "cg" (CSR; CG on the reduced operator: matrix-free
+    -- LinOpCg / LinMapsCg -- unless the explicit reduced matrix pays, see include/qps.h), "cg_explicit" (CSR; ItrSolCg: CG on the explicit
+    reduced matrix mPI + rho mAA, LinearSystemSolvers.jl:110-142) or "ldl" (CSR, sparse L D L' of the KKT matrix: the reference's direct plugins).
     """
 
     def __init__(self, mP, vQ, mA, vL, vU, *, linsys="cholesky", dtype="f64", device=0):
@@ -82,8 +83,8 @@ class QuadraticProgram:
         m = mA.shape[0]
         _validate_dims(n, mP, vQ, mA, vL, vU)
         self.n, self.m = n, m
-        self.linsys = {"cholesky": QPS_LINSYS_CHOLESKY, "cg": QPS_LINSYS_CG, "ldl": QPS_LINSYS_KKT_LDL, "auto": QPS_LINSYS_AUTO}[linsys]
-        csr = linsys in ("cg", "ldl")
+        self.linsys = {"cholesky": QPS_LINSYS_CHOLESKY, "cg": QPS_LINSYS_CG, "cg_explicit": QPS_LINSYS_CG_EXPLICIT, "ldl": QPS_LINSYS_KKT_LDL, "auto": QPS_LINSYS_AUTO}[linsys]
+        csr = linsys in ("cg", "cg_explicit", "ldl")
         dt = {"f64": QPS_F64, "f32": QPS_F32}[dtype]
         q, l, u = _vec(vQ, "vQ", n), _vec(vL, "vL", m), _vec(vU, "vU", m)
         h = C.c_void_p()
@@ -161,6 +162,16 @@ class QuadraticProgram:
                                                _dp(xx), _dp(zz)), self._h)
         vXX[:] = xx
         vZZ[:] = zz[:self.m]
+
+    # -- one application of the operator's matrices (qps_operator_apply) ----------------------------------------------
+    def apply(self, op, v, ρ=1.0, σ=0.0):
+        """``op`` in "P", "A", "At", "PA", "reduced": mP v, mA v, mA' v, [mP; mA] v, (mP + ρ mA'mA + σ I) v (LinearSystemSolvers.jl:152-157) through the
+        device kernels this handle's solves use for those products."""
+        kind = {"P": _lib.QPS_OP_P, "A": _lib.QPS_OP_A, "At": _lib.QPS_OP_AT, "PA": _lib.QPS_OP_PA, "reduced": _lib.QPS_OP_REDUCED}[op]
+        vin = _vec(v, "v", self.m if op == "At" else self.n)
+        out = np.zeros(max({"P": self.n, "A": self.m, "At": self.n, "PA": self.n + self.m, "reduced": self.n}[op], 1))
+        _lib.check(_lib.lib().qps_operator_apply(self._h, kind, _dp(vin if vin.size else np.zeros(1)), _dp(out), float(ρ), float(σ)), self._h)
+        return out[:{"P": self.n, "A": self.m, "At": self.n, "PA": self.n + self.m, "reduced": self.n}[op]]
 
     # -- profiling ----------------------------------------------------------------------------------------------------
     def set_profiling(self, level: int):
@@ -268,7 +279,7 @@ def _make_pair(linsys: str, dtype: str = "f64"):
         vZZ = np.zeros(numConstraints)
         return vXX, vZZ, [prob]
 
-    if linsys == "cg":
+    if linsys in ("cg", "cg_explicit"):
         def Sol(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ1, σ, numElements, numConstraints, changedΡ, *, ϵPcg=1e-6, numItrPcg=1000):
             tuSolver[0].linsys_solve(vX, vZ, vY, ρ, σ, changedΡ, vXX, vZZ, ϵPcg=ϵPcg, numItrPcg=numItrPcg)    # kwargs of LinearSystemSolvers.jl:164
     else:
@@ -282,6 +293,7 @@ def _make_pair(linsys: str, dtype: str = "f64"):
 
 HipCholInit, HipChol = _make_pair("cholesky")
 HipCgInit, HipCg = _make_pair("cg")
+HipItrSolCgInit, HipItrSolCg = _make_pair("cg_explicit")   # ItrSolCgInit / ItrSolCg!: cg! on the explicit reduced matrix (LinearSystemSolvers.jl:110-142)
 HipLdlInit, HipLdl = _make_pair("ldl")          # sparse L D L' of the KKT matrix: LaLdl / QDLdl / FacLdl (LinearSystemSolvers.jl:16-107)
 HipCholF32Init, HipCholF32 = _make_pair("cholesky", "f32")
 
@@ -298,7 +310,7 @@ def SolveQuadraticProgramInplace(vX, mP, vQ, mA, vL, vU, LinSysSolInit=HipCholIn
     linsys = getattr(LinSysSolInit, "_qps_linsys", None)
     if linsys is None or getattr(LinSysSol, "_qps_linsys", None) != linsys:
         raise TypeError("LinSysSolInit/LinSysSol must be one of this package's pairs (HipCholInit, HipChol) / "
-                        "(HipCgInit, HipCg) / (HipLdlInit, HipLdl): the device-resident loop has no CPU path")
+                        "(HipCgInit, HipCg) / (HipItrSolCgInit, HipItrSolCg) / (HipLdlInit, HipLdl): the device-resident loop has no CPU path")
     with QuadraticProgram(mP, vQ, mA, vL, vU, linsys=linsys, dtype=LinSysSolInit._qps_dtype, device=device) as prob:
         return prob.solve(vX, numIterations=numIterations, ϵAbs=ϵAbs, ϵRel=ϵRel, ρ=ρ, σ=σ, α=α, δ=δ, adptΡ=adptΡ,
                           fctrΡ=fctrΡ, numItrConv=numItrConv, numItrPolish=numItrPolish, ϵMinres=ϵMinres,
