@@ -214,6 +214,21 @@ int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, const double
                                const double *l, const double *u, int32_t dtype, int32_t device, qps_handle *out);
 int32_t qps_solve_batch(qps_handle h, double *x_inout, const qps_params *params, qps_info *infos);
 
+/* The per-problem loop of RunBenchmarks.jl:88-104 sharded over the devices of ONE process ("one host thread + one stream per device", "work-stealing at
+ * chunk boundaries").  `count` independent dense QPs of one shape, arrays stacked as for qps_create_dense_batch; `devices[num_workers]` lists the device of every worker
+ * -- one host thread each; a device may be listed more than once (two workers sharing a card).  Every worker repeatedly takes the next range of QPs from a shared
+ * counter -- `chunk` of them at first, fewer towards the end of the batch: clamp(ceil(remaining / (2 W)), max(1, chunk / 4), chunk) -- builds a batch handle for them on
+ * its device, solves them (qps_solve_batch) and drops the handle: a run to a tolerance, in which every QP stops at its own iteration, balances itself.  chunk <= 0:
+ * static contiguous slabs, worker w takes QPs [w * ceil(count / W), ...) -- what a fixed-K run wants (equal work per QP, no hand-out).  The size of a range depends
+ * only on where it starts, so the ranges are cut the same way whoever solves them: the results do not depend on timing or on which worker took a range, and they
+ * equal qps_solve_batch on batches of those same ranges bit for bit.  No data-path collective, no exchange between devices.
+ * x_inout [count][n] (warm starts in, solutions out), infos [count] (may be NULL), worker_of [count] (may be NULL: which worker solved QP b), worker_seconds
+ * [num_workers] (may be NULL: busy time per worker, handle creation included).  On an error the other workers stop at their next chunk boundary and the first error is
+ * returned (qps_last_error(NULL) on the calling thread). */
+int32_t qps_solve_batch_multi(int64_t count, int64_t n, int64_t m, const double *P, const double *A, const double *q, const double *l, const double *u,
+                              int32_t dtype, const int32_t *devices, int32_t num_workers, int32_t chunk, double *x_inout, const qps_params *p, qps_info *infos,
+                              int32_t *worker_of, double *worker_seconds);
+
 /* Device-time of the loop kernels of the last qps_solve, measured with HIP events attached to the kernel dispatches
  * themselves (hipExtLaunchKernelGGL start / stop events on the solver's stream: the dispatch's own begin / end timestamps)
  * (used by bench.py's roofline block).  names is a caller buffer of `cap` entries; returns the number filled. */

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "qps_linsys_init", "qps_linsys_solve", "qps_create_dense_batch", "qps_solve_batch", "qps_kernel_times",
     "qps_set_profiling", "qps_destroy", "qps_last_error", "qps_version",
     "qps_proxqp_default_params", "qps_proxqp_create_dense", "qps_proxqp_init_kkt", "qps_proxqp_set_state", "qps_proxqp_get_state",
-    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze", "qps_proxqp_create_csc", "qps_linsys_set_cg", "qps_operator_apply",
+    "qps_proxqp_solve", "qps_polish", "qps_linsys_auto", "qps_ldl_analyze", "qps_proxqp_create_csc", "qps_linsys_set_cg", "qps_operator_apply", "qps_solve_batch_multi",
 ]
 
 QPS_OK = 0
@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
     L.qps_operator_apply.argtypes = [hp, i32, dp, dp, dbl, dbl]
     L.qps_create_dense_batch.argtypes = [i64, i64, i64, dp, dp, dp, dp, dp, i32, i32, C.POINTER(hp)]
     L.qps_solve_batch.argtypes = [hp, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo)]
+    L.qps_solve_batch_multi.argtypes = [i64, i64, i64, dp, dp, dp, dp, dp, i32, C.POINTER(i32), i32, i32, dp, C.POINTER(QpsParams), C.POINTER(QpsInfo), C.POINTER(i32), dp]
     L.qps_kernel_times.argtypes = [hp, C.POINTER(QpsKernelTime), i32, C.POINTER(i32)]
     L.qps_set_profiling.argtypes = [hp, i32]
     L.qps_proxqp_default_params.argtypes = [C.POINTER(QpsProxQpParams)]

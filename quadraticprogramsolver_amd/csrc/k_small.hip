@@ -509,7 +509,7 @@ void admm_small(hipStream_t st, int n, int m, int NP, int MP, int it_begin, int 
     const int ti = sizeof(T) == 8 ? 0 : 1, dev_ = current_device();
 #define QPS_SMALL(THN, IDX, LMV)                                                                                                             \
     do {                                                                                                                                     \
-        if (attr_set[ti][IDX][LMV].first(dev_)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN, (LMV) != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attr_set[ti][IDX][LMV].once(dev_, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_admm_small<T, THN, (LMV) != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((k_admm_small<T, THN, (LMV) != 0>), dim3(1), dim3(THN), lds, st, a, A, At, P, S, q, l, u, x, xp, z, y, reinterpret_cast<SmallOut*>(out_dev)); \
     } while (0)
 #define QPS_SMALL2(THN, IDX) do { if (lm) QPS_SMALL(THN, IDX, 1); else QPS_SMALL(THN, IDX, 0); } while (0)

@@ -310,7 +310,7 @@ void trsv_blocked(hipStream_t st, bool bwd, const T* S, int64_t ld, int NP, int 
     do {                                                                                                                                \
         auto kern = k_trsv_blocked<T, STREAM, BWDV, WIN>;                                                                               \
         static PerDeviceOnce attr_done;   /* the attribute lives in the device's code object: once per device ordinal */                \
-        if (attr_done.first(dev_)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
+        attr_done.once(dev_, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); }); \
         if (lt.start) hipExtLaunchKernelGGL(kern, dim3(TBG), dim3(STREAM + 64), lds, st, lt.start, lt.stop, 0, S, ld, NP, v, out, pub, (int64_t)NP, epoch, abort_word, spin_limit, mode); \
         else hipLaunchKernelGGL(kern, dim3(TBG), dim3(STREAM + 64), lds, st, S, ld, NP, v, out, pub, (int64_t)NP, epoch, abort_word, spin_limit, mode); \
     } while (0)

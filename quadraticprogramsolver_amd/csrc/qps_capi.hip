@@ -4,6 +4,10 @@
 // LinearSystemSolvers.jl:110-142 with cg! replaced by Cholesky + two triangular sweeps (ProxQP.jl:175-206,221-225).
 // There is NO CPU fallback: without a HIP device every entry point fails with QPS_ERR_NO_DEVICE.
 #include "ldl_symbolic.h"
+#include <atomic>
+#include <thread>
+
+#include "batch_schedule.h"
 #include "qps_internal.h"
 #include "spmv_layout.h"
 #include "qps_kernels.h"
@@ -1161,6 +1165,43 @@ QPS_API int32_t qps_solve_batch(qps_handle hh, double* x, const qps_params* p, q
         rc = guarded(h, [&] { h->batch[b]->solve(x + (int64_t)b * h->n, *p, infos ? infos + b : nullptr); });
         if (rc != QPS_OK) return rc;
     }
+    return QPS_OK;
+}
+
+QPS_API int32_t qps_solve_batch_multi(int64_t count, int64_t n, int64_t m, const double* P, const double* A, const double* q, const double* l, const double* u,
+                                      int32_t dtype, const int32_t* devices, int32_t num_workers, int32_t chunk, double* x, const qps_params* p, qps_info* infos,
+                                      int32_t* worker_of, double* worker_seconds) {
+    if (count <= 0 || n <= 0 || m < 0) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "need count >= 1, n >= 1 and m >= 0");
+    if (!P || !q || !x || (m > 0 && (!A || !l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
+    if (!devices || num_workers <= 0 || num_workers > 256) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "need 1..256 workers and their device list");
+    if (chunk > 65535) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "chunk must be at most 65535 (the batch handle's limit)");
+    {
+        const int rc = validate_params(nullptr, p);
+        if (rc != QPS_OK) return rc;
+    }
+    for (int w = 0; w < num_workers; ++w) {
+        const int dc = check_device(devices[w]);
+        if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
+        if (dc != QPS_OK) return fail_with(nullptr, dc, "device index out of range in the worker list");
+    }
+    std::mutex err_mu; std::string err_msg; int err_code = QPS_OK;
+    auto solve_range = [&](int w, int64_t b0, int64_t cnt) -> int {
+        qps_handle h = nullptr;
+        int rc = qps_create_dense_batch(cnt, n, m, P + b0 * n * n, A ? A + b0 * m * n : nullptr, q + b0 * n, l ? l + b0 * m : nullptr, u ? u + b0 * m : nullptr, dtype,
+                                        devices[w], &h);
+        if (rc == QPS_OK) rc = qps_solve_batch(h, x + b0 * n, p, infos ? infos + b0 : nullptr);
+        if (rc != QPS_OK) {
+            std::lock_guard<std::mutex> lk(err_mu);
+            if (err_code == QPS_OK) { err_code = rc; const char* msg = qps_last_error(h); err_msg = msg ? msg : ""; }   // (the message lives on this worker's thread)
+        } else if (worker_of) {
+            for (int64_t b = b0; b < b0 + cnt; ++b) worker_of[b] = w;
+        }
+        if (h) (void)qps_destroy(h);
+        return rc;
+    };
+    // one host thread per worker, ranges dealt as batch_schedule.h describes (65535: the batch handle's limit)
+    (void)run_batch_workers(count, num_workers, chunk, 65535, solve_range, worker_seconds);
+    if (err_code != QPS_OK) return fail_with(nullptr, err_code, err_msg);
     return QPS_OK;
 }
 

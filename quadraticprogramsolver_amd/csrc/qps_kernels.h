@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <thread>
 
 namespace qps {
 
@@ -23,10 +24,18 @@ namespace qps {
 constexpr int kMaxDevices = 64;
 int current_device();                 // hipGetDevice (the entry points of a handle make its device current first)
 int device_cu_count(int device);      // multiProcessorCount, asked once per ordinal
-// "has this been done on device d yet?" for per-device one-time settings such as hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+// Per-device one-time settings such as hipFuncSetAttribute(MaxDynamicSharedMemorySize): `once(dev, f)` runs f exactly once per device ordinal and returns,
+// on EVERY calling thread, only after f has returned -- a second host thread (distinct handles may be driven from distinct threads, include/qps.h:19) must
+// not launch the kernel before the attribute is in place (its launch with 144-160 KiB of dynamic LDS would fail).
 struct PerDeviceOnce {
-    std::atomic<unsigned char> done[kMaxDevices] = {};
-    bool first(int dev) { if (dev < 0 || dev >= kMaxDevices) return true; return done[dev].exchange(1, std::memory_order_acq_rel) == 0; }
+    std::atomic<unsigned char> state[kMaxDevices] = {};          // 0 not started, 1 running, 2 done
+    template <typename F> void once(int dev, F&& f) {
+        if (dev < 0 || dev >= kMaxDevices) { f(); return; }
+        if (state[dev].load(std::memory_order_acquire) == 2) return;
+        unsigned char expect = 0;
+        if (state[dev].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) { f(); state[dev].store(2, std::memory_order_release); return; }
+        while (state[dev].load(std::memory_order_acquire) != 2) std::this_thread::yield();
+    }
 };
 
 // A launcher that finds a pending event pair here attaches it to its kernel dispatch (hipExtLaunchKernelGGL): the events then carry the

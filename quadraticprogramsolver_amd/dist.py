@@ -60,6 +60,45 @@ def shard_assign(total: int, rank: int, world_size: int, assign: str = "contiguo
     raise ValueError(f"unknown assignment {assign!r}")
 
 
+def handout_ranges(total: int, workers: int, chunk: int):
+    """The ranges qps_solve_batch_multi cuts a batch into (quadraticprogramsolver_amd/csrc/batch_schedule.h), in hand-out order: chunk > 0 -- guided self-scheduling,
+    take(b) = clamp(ceil(remaining / (2 W)), max(1, chunk / 4), chunk); chunk <= 0 -- one contiguous slab per worker."""
+    if chunk <= 0:
+        slab = max(1, -(-total // workers))
+        return [(b, min(slab, total - b)) for b in range(0, total, slab)]
+    out, b, smallest = [], 0, max(1, chunk // 4)
+    while b < total:
+        rem = total - b
+        k = min(rem, max(smallest, min(chunk, -(-rem // (2 * workers)))))
+        out.append((b, k)); b += k
+    return out
+
+
+def handout_schedule(work, workers: int, chunk: int, lockstep: bool = False):
+    """Event simulation of the in-process hand-out: the ranges of `handout_ranges`, each to the worker that becomes free first (ties: lowest index; static slabs:
+    worker = slab index modulo workers).  Cost of a range: the sum of its QPs' work, or -- ``lockstep`` -- (its longest QP) x (its size): a batched handle advances
+    its QPs together, and a small range is launch-bound rather than bandwidth-bound.  Returns (worker of every QP, load per worker)."""
+    import heapq
+    total = len(work)
+    cost = (lambda v: max(v) * len(v)) if lockstep else sum
+    load = [0.0] * workers
+    owner = [0] * total
+    free = [(0.0, w) for w in range(workers)]
+    heapq.heapify(free)
+    for i, (b, k) in enumerate(handout_ranges(total, workers, chunk)):
+        if chunk <= 0:
+            w, t = i % workers, load[i % workers]
+        else:
+            t, w = heapq.heappop(free)
+        c = float(cost([float(x) for x in work[b:b + k]]))
+        load[w] += c
+        if chunk > 0:
+            heapq.heappush(free, (t + c, w))
+        for j in range(b, b + k):
+            owner[j] = w
+    return owner, load
+
+
 def init_process_group(info: RankInfo, prefer: str | None = None):
     """Returns the backend actually in use ("nccl" == RCCL on ROCm, or "gloo"), or None for a single process.
 

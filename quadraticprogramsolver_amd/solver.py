@@ -207,9 +207,16 @@ class QuadraticProgramBatch:
     the per-problem loop of RunBenchmarks.jl:88-104 advanced in lock step by batched launches.  Every QP keeps its own
     rho, proposed rho, convergence flag and stopping iteration, exactly as if solved alone."""
 
-    def __init__(self, problems, *, dtype="f64", device=0):
-        """``problems``: sequence of (mP, vQ, mA, vL, vU) tuples with identical shapes (dense or scipy sparse)."""
+    def __init__(self, problems, *, dtype="f64", device=0, devices=None, chunk=0):
+        """``problems``: sequence of (mP, vQ, mA, vL, vU) tuples with identical shapes (dense or scipy sparse).
+
+        ``devices`` (a list of device ordinals, one entry per worker; a device may appear more than once) selects the in-process multi-device driver
+        (qps_solve_batch_multi): one host thread per entry, each taking ranges of at most ``chunk`` QPs from a shared counter (``chunk`` <= 0: one contiguous slab
+        per worker).  The problem data then stays on the host and every ``solve`` builds and drops the per-range batch handles; ``dual`` is not available."""
         self.count = len(problems)
+        self.devices = None if devices is None else [int(d) for d in devices]
+        self.chunk = int(chunk)
+        self.worker_of, self.worker_seconds = None, None
         mP0, _, mA0, _, _ = problems[0]
         self.n, self.m = mP0.shape[0], mA0.shape[0]
         dense = lambda M: np.asarray(M.toarray() if sp.issparse(M) else M, dtype=np.float64)
@@ -224,6 +231,12 @@ class QuadraticProgramBatch:
         u = np.ascontiguousarray(np.stack([_vec(p[4], "vU", self.m) for p in problems])) if self.m > 0 else np.zeros((self.count, 1))
         h = C.c_void_p()
         dt = {"f64": QPS_F64, "f32": QPS_F32}[dtype]
+        if self.devices is not None:
+            if not self.devices:
+                raise ValueError("devices must list at least one worker")
+            self._host = (P, A, q, l, u, dt)
+            self._h = None
+            return
         _lib.check(_lib.lib().qps_create_dense_batch(self.count, self.n, self.m, _dp(P), _dp(A), _dp(q), _dp(l), _dp(u), dt, device, C.byref(h)))
         self._h = h
 
@@ -238,11 +251,23 @@ class QuadraticProgramBatch:
         p.trsvBlock, p.reuseFactor = int(trsvBlock), int(bool(reuseFactor))
         p.polish, p.numItrPolish, p.delta, p.epsMinres, p.numItrMinres = int(bool(polish)), int(numItrPolish), float(δ), float(ϵMinres), int(numItrMinres)
         infos = (QpsInfo * self.count)()
+        if self.devices is not None:
+            P, A, q, l, u, dt = self._host
+            W = len(self.devices)
+            devs = (C.c_int32 * W)(*self.devices)
+            owner = (C.c_int32 * self.count)()
+            secs = (C.c_double * W)()
+            _lib.check(_lib.lib().qps_solve_batch_multi(self.count, self.n, self.m, _dp(P), _dp(A), _dp(q), _dp(l), _dp(u), dt, devs, W, self.chunk, _dp(X), C.byref(p), infos,
+                                                        owner, secs))
+            self.worker_of, self.worker_seconds = list(owner), list(secs)
+            return X, [ConvergenceFlag(i.convFlag) for i in infos], [i.as_dict() for i in infos]
         _lib.check(_lib.lib().qps_solve_batch(self._h, _dp(X), C.byref(p), infos), self._h)
         return X, [ConvergenceFlag(i.convFlag) for i in infos], [i.as_dict() for i in infos]
 
     def dual(self):
         """(mZ, mY) [count x m] of the last solve (additive: the reference discards them)."""
+        if self.devices is not None:
+            raise RuntimeError("dual() is not available in multi-device mode (the per-range handles are dropped after their solve)")
         Z = np.zeros((self.count, max(self.m, 1)))
         Y = np.zeros((self.count, max(self.m, 1)))
         if self.m > 0:

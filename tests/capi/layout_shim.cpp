@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "../../quadraticprogramsolver_amd/csrc/batch_schedule.h"
 #include "../../quadraticprogramsolver_amd/csrc/ldl_symbolic.h"
 #include "../../quadraticprogramsolver_amd/csrc/spmv_layout.h"
 
@@ -107,6 +108,18 @@ SHIM_API int64_t lt_reduced_matrix(int64_t n, int64_t m, const int64_t* Pcp, con
         }
         return (int64_t)L.ci.size();
     } catch (const std::exception&) { return -2; }
+}
+// The hand-out of qps_solve_batch_multi (batch_schedule.h) with a stand-in for the solve: "solving" QP b takes cost_us[b] microseconds of wall time (sleep), a range
+// takes the sum of its QPs.  worker_of[count] / solved[count] (how often each QP was solved) / worker_seconds[workers] out.  fail_at >= 0: the range holding that QP
+// reports an error (the hand-out must stop).  Returns what run_batch_workers returns.
+SHIM_API int lt_schedule(int64_t count, int workers, int64_t chunk, const double* cost_us, int* worker_of, int* solved, double* worker_seconds, int64_t fail_at) {
+    auto solve = [&](int w, int64_t b0, int64_t cnt) -> int {
+        double us = 0;
+        for (int64_t b = b0; b < b0 + cnt; ++b) { us += cost_us[b]; worker_of[b] = w; __atomic_fetch_add(&solved[b], 1, __ATOMIC_RELAXED); }
+        std::this_thread::sleep_for(std::chrono::duration<double, std::micro>(us));
+        return (fail_at >= b0 && fail_at < b0 + cnt) ? 7 : 0;
+    };
+    return run_batch_workers(count, workers, chunk, 65535, solve, worker_seconds);
 }
 // the symbolic analysis of the sparse direct KKT plugin (what qps_ldl_analyze exports from the product library): perm[new] = old, report[8]
 SHIM_API int lt_ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri, const int64_t* Acp, const int64_t* Ari, int base, int max_tail, int min_level, int max_levels,

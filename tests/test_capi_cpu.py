@@ -334,7 +334,7 @@ def test_no_function_local_static_guards_per_device_hip_state():
         for i, line in enumerate(lines):
             if "hipFuncSetAttribute" in line:
                 ctx = " ".join(lines[max(0, i - 3):i + 1])
-                if ".first(" not in ctx and "launch_is_co_resident" not in " ".join(lines[max(0, i - 12):i + 1]):
+                if ".once(" not in ctx and "launch_is_co_resident" not in " ".join(lines[max(0, i - 12):i + 1]):
                     offenders.append(f"{os.path.basename(path)}:{i + 1}: hipFuncSetAttribute not behind a per-device once-flag")
             if re.search(r"\bstatic\b(?!\s+(constexpr|inline|__device__|__global__|PerDeviceOnce))", line) and re.search(
                     r"hipGetDeviceProperties|hipDeviceGetAttribute|hipOccupancyMaxActiveBlocks|multiProcessorCount|hipGetDevice\(", " ".join(lines[i:i + 3])):

@@ -47,6 +47,66 @@ def test_balanced_assignments_cover_the_batch_and_even_out_the_work():
         qd.shard_assign(8, 0, 2, assign="nope")
 
 
+def _c4_counts():
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return json.load(open(os.path.join(root, "tests", "golden", "c4_time_to_eps_iterations.json")))["iterations"]
+
+
+def test_dynamic_handout_balances_a_run_to_a_tolerance():
+    """The in-process multi-device driver (qps_solve_batch_multi, batch_schedule.h; SURVEY 8e "work-stealing at chunk boundaries") on the recorded per-QP iteration
+    counts of BASELINE config 4: ranges of at most `chunk` QPs, shrinking towards the end of the batch, each to the worker that frees first.  The ranges tile the batch;
+    at 8 workers and chunk = 8 the makespan stays within 3 % of the mean load under both cost models (bandwidth-bound: the sum of a range's iterations; lock step: its
+    longest QP x its size) -- where the static contiguous slabs are 5-10 % off and need no knowledge either, and LPT's 0.8 % needs the answer in advance."""
+    work = _c4_counts()
+    for workers in (2, 4, 8):
+        for chunk in (8, 16, 32):
+            ranges = qd.handout_ranges(256, workers, chunk)
+            assert ranges[0] == (0, min(chunk, max(chunk // 4, -(-256 // (2 * workers)))))
+            assert all(a + k == b for (a, k), (b, _) in zip(ranges[:-1], ranges[1:])) and ranges[-1][0] + ranges[-1][1] == 256
+            assert all(1 <= k <= chunk for _, k in ranges)
+    over = {}
+    for lockstep in (False, True):
+        owner, load = qd.handout_schedule(work, 8, 8, lockstep=lockstep)
+        assert sorted(set(owner)) == list(range(8))
+        over[lockstep] = max(load) / (sum(load) / 8) - 1.0
+    assert over[False] <= 0.03 and over[True] <= 0.03, over
+    _, static = qd.handout_schedule(work, 8, 0)
+    assert max(static) / (sum(static) / 8) - 1.0 > over[False]                  # the slabs of a fixed-K run are worse on a run to a tolerance
+    assert qd.handout_ranges(256, 8, 0) == [(32 * w, 32) for w in range(8)]     # chunk <= 0: QP b -> worker b // 32, as bench.py's slabs
+
+
+def test_the_handout_itself_with_a_stand_in_for_the_solve():
+    """batch_schedule.h as the library runs it -- real host threads, a shared counter -- through the host test library (tests/capi/layout_shim.cpp), the solve replaced by
+    a sleep proportional to the recorded iteration counts: every QP solved exactly once, the ranges are those of `handout_ranges` whoever took them, the loads (from the
+    recorded counts, not from the wall clock) stay within 8 % of the mean at 8 workers, an error in one range stops the hand-out, chunk <= 0 gives the static slabs."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("QPS_HOST_TEST_LIB")
+    if not path:
+        subprocess.check_call(["make", "-C", os.path.join(root, "quadraticprogramsolver_amd", "csrc"), "-s", "host-test"])
+        path = os.path.join(root, "quadraticprogramsolver_amd", "libqps_host_test.so")
+    L = C.CDLL(path)
+    L.lt_schedule.argtypes = [C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int64]
+    work = _c4_counts()
+    cost = (C.c_double * 256)(*[w * 2.0 for w in work])                          # 2 us per iteration: ~0.34 s of sleep in all
+    for workers, chunk in ((8, 8), (3, 16), (8, 0)):
+        owner, solved, secs = (C.c_int * 256)(), (C.c_int * 256)(), (C.c_double * workers)()
+        assert L.lt_schedule(256, workers, chunk, cost, owner, solved, secs, -1) == 0
+        assert list(solved) == [1] * 256
+        for b, k in qd.handout_ranges(256, workers, chunk):                      # a range is solved by ONE worker, whoever it was
+            assert len(set(owner[b:b + k])) == 1, (workers, chunk, b, k)
+        load = [sum(work[b] for b in range(256) if owner[b] == w) for w in range(workers)]
+        if chunk > 0:
+            assert max(load) / (sum(load) / workers) - 1.0 <= 0.08, (workers, chunk, load)
+        else:
+            assert list(owner) == [b // 32 for b in range(256)]
+    owner, solved, secs = (C.c_int * 256)(), (C.c_int * 256)(), (C.c_double * 4)()
+    assert L.lt_schedule(256, 4, 8, cost, owner, solved, secs, 40) == 7           # the range holding QP 40 fails: its code comes back ...
+    assert sum(solved) < 256                                                     # ... and the hand-out stopped early
+
+
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     info = qd.rank_info_from_env()
