@@ -35,7 +35,10 @@ struct HipCgInitT end;    const HipCgInit = HipCgInitT()          # CSR matrix-f
 struct HipCgT end;        const HipCg! = HipCgT()
 struct HipLdlInitT end;   const HipLdlInit = HipLdlInitT()        # sparse L D L' of the KKT matrix on the device: the counterpart of
 struct HipLdlT end;       const HipLdl! = HipLdlT()               # LaLdlInit/LaLdl!, QDLdlInit/QDLdl!, FacLdlInit/FacLdl! (LinearSystemSolvers.jl:16-107)
-const QPS_LINSYS_CHOLESKY = Int32(1); const QPS_LINSYS_CG = Int32(2); const QPS_LINSYS_KKT_LDL = Int32(3)
+struct HipItrSolCgInitT end; const HipItrSolCgInit = HipItrSolCgInitT()   # cg! on the EXPLICIT reduced matrix mPI + ρ mAA on the device: the counterpart of
+struct HipItrSolCgT end;     const HipItrSolCg! = HipItrSolCgT()          # ItrSolCgInit / ItrSolCg! (LinearSystemSolvers.jl:110-142)
+const QPS_LINSYS_CHOLESKY = Int32(1); const QPS_LINSYS_CG = Int32(2); const QPS_LINSYS_KKT_LDL = Int32(3); const QPS_LINSYS_CG_EXPLICIT = Int32(4)
+const QPS_OP_P = Int32(0); const QPS_OP_A = Int32(1); const QPS_OP_AT = Int32(2); const QPS_OP_PA = Int32(3); const QPS_OP_REDUCED = Int32(4)   # qps_operator_kind
 # arithmetic type of the device-resident loop (qps_dtype): the boundary always carries Float64 arrays, `dtype = Float32` runs the loop in fp32
 _dtype(::Type{Float64}) = Int32(0)
 _dtype(::Type{Float32}) = Int32(1)
@@ -96,6 +99,7 @@ end
 # Same positional order and keyword names as SolveQuadraticProgram.jl:14-17
 SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipCholInitT, ::HipCholT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, true; kw...)
 SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipCgInitT, ::HipCgT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, false; kw...)
+SolveQuadraticProgram!(vX, mP, vQ, mA, vL, vU, ::HipItrSolCgInitT, ::HipItrSolCgT; kw...) = _solve!(vX, mP, vQ, mA, vL, vU, false, QPS_LINSYS_CG_EXPLICIT; kw...)
 # RunTests.jl:55-56 / RunBenchmarks.jl:54-55 select FacLdlInit / FacLdl!; the device counterpart takes the same SparseMatrixCSC inputs
 SolveQuadraticProgram!(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, vL, vU, ::HipLdlInitT, ::HipLdlT; kw...) =
     _solve!(vX, mP, vQ, mA, vL, vU, false, QPS_LINSYS_KKT_LDL; kw...)
@@ -162,6 +166,46 @@ function (::HipCgT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, nu
     _check(ccall((:qps_linsys_set_cg, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Int32), h, ϵPcg, numItrPcg), h)
     HipChol!(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ)   # same qps_linsys_solve call
     return
+end
+
+# ItrSolCgInit / ItrSolCg! literally (LinearSystemSolvers.jl:110-142): Init forms mAA = mA'mA, mPI = mP + σI and mL = mPI + ρ mAA on the device handle (:112-114),
+# Sol! rebuilds mL from the cached parts on changedΡ (:127-129) and runs cg! with ONE product per iteration (:137); same kwargs as the other CG plugins (:125)
+function (::HipItrSolCgInitT)(vX, mP::SparseMatrixCSC, vQ, mA::SparseMatrixCSC, ρ, ρ¹, σ, numElements, numConstraints)
+    h = _create(mP, Vector{Float64}(vQ), mA, zeros(numConstraints), zeros(numConstraints); densePath = false)
+    _check(ccall((:qps_linsys_init, LIBQPS), Int32, (Ptr{Cvoid}, Float64, Float64, Int32, Int32), h, ρ, σ, QPS_LINSYS_CG_EXPLICIT, 0), h)
+    return zeros(numElements), zeros(numConstraints), Any[HipLinSys(h)]
+end
+(::HipItrSolCgT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ; ϵPcg = 1e-6, numItrPcg = 1000) =
+    HipCg!(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ; ϵPcg = ϵPcg, numItrPcg = numItrPcg)   # same two calls
+
+# One application of the operator's matrices on the device (qps_operator_apply): kind = QPS_OP_P / _A / _AT / _PA / _REDUCED -- mP v, mA v, mA' v, [mP; mA] v and
+# (mP + ρ mA'mA + σI) v, the operator of LinOpCgInit (LinearSystemSolvers.jl:152-157) -- through the kernels the handle's solves use for those products
+function ApplyOperator(tuSolver, kind::Int32, vV::Vector{Float64}; ρ = 1.0, σ = 0.0, numElements::Int, numConstraints::Int)
+    h = tuSolver[1].h
+    vOut = zeros(kind == QPS_OP_A ? numConstraints : (kind == QPS_OP_PA ? numElements + numConstraints : numElements))
+    GC.@preserve vV vOut _check(ccall((:qps_operator_apply, LIBQPS), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Float64), h, kind, vV, vOut, ρ, σ), h)
+    return vOut
+end
+
+# The per-problem loop of RunBenchmarks.jl:88-104 over the GPUs of this process (qps_solve_batch_multi): tProblems = vector of (mP, vQ, mA, vL, vU) dense tuples of one
+# shape, vDevices = the device of every worker (one host thread each inside the library), chunk = the largest range a worker takes from the shared counter
+# (0: one contiguous slab per worker, for fixed-K runs).  Returns (mX [n x count], vector of ConvergenceFlag, vector of QpsInfo, worker of every problem).
+function SolveQuadraticProgramBatch(tProblems::Vector, vDevices::Vector{<:Integer}; chunk::Integer = 0, dtype::Type = Float64, numIterations = 5000, ϵAbs = 1e-6, ϵRel = 1e-6,
+                                    ρ = 1, σ = 1e-6, α = 1.6, adptΡ::Bool = false, fctrΡ = 5, numItrConv = 25)
+    count = length(tProblems); n = size(tProblems[1][1], 1); m = size(tProblems[1][3], 1)
+    mPs = reduce(hcat, [vec(Matrix{Float64}(t[1])) for t in tProblems]); mAs = reduce(hcat, [vec(Matrix{Float64}(t[3])) for t in tProblems])   # column b = problem b, column-major
+    mQ = reduce(hcat, [Vector{Float64}(t[2]) for t in tProblems]); mL = reduce(hcat, [Vector{Float64}(t[4]) for t in tProblems]); mU = reduce(hcat, [Vector{Float64}(t[5]) for t in tProblems])
+    mX = zeros(n, count); vInfo = [QpsInfo() for _ in 1:count]; vWorker = zeros(Int32, count); vSeconds = zeros(length(vDevices))
+    prm = QpsParams(numIterations, adptΡ, numItrConv, 10, 500, 0, 0, 0, ϵAbs, ϵRel, ρ, σ, α, 1e-6, fctrΡ, 1e-6, 1e-6, 1000, 0, 0, 0)
+    vRaw = Vector{UInt8}(undef, count * sizeof(QpsInfo))                      # qps_info records land here (QpsInfo is mutable: not stored inline in a Vector)
+    vDev = Vector{Int32}(vDevices)
+    GC.@preserve mPs mAs mQ mL mU mX vRaw vDev vWorker vSeconds _check(ccall((:qps_solve_batch_multi, LIBQPS), Int32,
+        (Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Int32}, Int32, Int32, Ptr{Float64}, Ref{QpsParams}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}),
+        count, n, m, mPs, mAs, mQ, mL, mU, _dtype(dtype), vDev, Int32(length(vDev)), Int32(chunk), mX, Ref(prm), vRaw, vWorker, vSeconds))
+    for b in 1:count
+        unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(vInfo[b])), pointer(vRaw, (b - 1) * sizeof(QpsInfo) + 1), sizeof(QpsInfo))
+    end
+    return mX, [ConvergenceFlag(i.convFlag) for i in vInfo], vInfo, vWorker
 end
 
 function (::HipCholT)(tuSolver, vXX, vZZ, vX, mP, vQ, mA, vZ, vY, ρ, ρ¹, σ, numElements, numConstraints, changedΡ)

@@ -194,6 +194,28 @@ def test_sparse_kkt_initialisation_with_singular_p_and_loud_failure(gpu):
     assert e.value.status == 4 and ("did not converge" in e.value.message or "pivot" in e.value.message)
 
 
+def test_sparse_kkt_initialisation_with_a_small_eigenvalue_of_p_in_fp32(gpu):
+    """Advisor (round 3): in the directions of P that A does not pin, a refinement step against the unshifted system contracts only by delta / (lambda + delta); with
+    fp32's delta = 1e-3 and lambda_min(P) = 1e-4 (0.91 per step) the old fixed count of 7 steps left a relative residual of 0.5 and the handle was refused, where the
+    reference's `mK \\ vR` (ProxQP.jl:103-106) simply solves.  No equality rows at all: every direction is unpinned.  The start must come out close to -P^-1 q and the
+    solve must converge from it, in both precisions."""
+    import scipy.sparse as sp
+    rng = make_rng(1518, 5)
+    n, mi = 300, 200
+    dvals = np.concatenate([np.full(20, 1e-4), 0.5 + rng.random(n - 20)])         # twenty directions with lambda = 1e-4
+    P = sp.diags(dvals).tocsc()
+    A = sp.csc_matrix((0, n)); b = np.zeros(0)
+    C = sp.random(mi, n, density=0.05, random_state=np.random.default_rng(8), data_rvs=rng.standard_normal, format="csc")
+    q = rng.standard_normal(n) * np.where(dvals < 1e-3, 1e-4, 1.0)               # keeps -P^-1 q of order one
+    d = np.abs(rng.standard_normal(mi)) + 20.0                                   # inactive at the start
+    ref = -q / dvals
+    for dtype, tol in (("f64", 1e-7), ("f32", 5e-2)):                            # (a residual of 1e-12 over lambda = 1e-4 is an error of 1e-8)
+        with gpu.ProxQP(P, q, A, b, C, d, dtype=dtype) as prob:
+            assert rel(prob.vX, ref) <= tol, (dtype, rel(prob.vX, ref))
+            rep = gpu.SolveQuadraticProgramProxQP(prob, numIterations=2000, ϵAbs=1e-6 if dtype == "f64" else 1e-3, ϵRel=1e-6 if dtype == "f64" else 1e-3)
+            assert rep["Converged"], (dtype, rep)
+
+
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 2e-3)])
 def test_sparse_reported_primal_residual_is_the_true_one_at_large_rho(gpu, dtype, tol):
     """CheckConvergence! recomputes mA * vX and mC * vX (ProxQP.jl:264-265).  With rho at 1e5 the KKT system [P + sigma I, G'; G, -I/rho] is solved
