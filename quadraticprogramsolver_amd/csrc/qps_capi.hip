@@ -55,6 +55,35 @@ void recycle_resources(int device, HandleResources r) {
     if (r.pinned) (void)hipHostFree(r.pinned);
     if (r.st) (void)hipStreamDestroy(r.st);
 }
+int host_threads() {
+    static const int n = [] {
+        const char* e = getenv("QPS_HOST_THREADS");
+        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        return std::max(1, std::min(e ? atoi(e) : 8, hw));
+    }();
+    return n;
+}
+namespace {
+constexpr size_t kRingHalf = (size_t)32 << 20;
+std::vector<PinnedRing> g_rings[kMaxDevices];
+}  // namespace
+PinnedRing acquire_ring(int device) {
+    PinnedRing r;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (device >= 0 && device < kMaxDevices && !g_rings[device].empty()) { r = g_rings[device].back(); g_rings[device].pop_back(); }
+    }
+    if (!r.base) { HIPC(hipHostMalloc((void**)&r.base, 2 * kRingHalf)); r.half = kRingHalf; }
+    return r;
+}
+void recycle_ring(int device, PinnedRing r) {
+    if (!r.base) return;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        if (device >= 0 && device < kMaxDevices && (int)g_rings[device].size() < kRecyclePerDevice) { g_rings[device].push_back(r); return; }
+    }
+    (void)hipHostFree(r.base);
+}
 thread_local LaunchTiming g_launch_timing;
 ProfLaunchScope::ProfLaunchScope(Profiler& pr, int c, int lvl) : p(pr), cat(c), a(nullptr), b(nullptr), active(pr.on(lvl)) {
     if (active) { a = p.get(); b = p.get(); g_launch_timing.start = a; g_launch_timing.stop = b; }
@@ -222,10 +251,11 @@ template <typename T> struct DenseSolver : SolverBase {
         int pc = (int)std::max<int64_t>(64, (budget / std::max(rows, 1)) / 64 * 64);
         double* buf = nullptr;
         HIPC(hipMalloc((void**)&buf, sizeof(double) * (size_t)rows * (size_t)std::min(pc, cols)));
+        FastUploader fu(st, device);                 // pinned ring filled by several host threads (qps_internal.h)
         for (int c0 = 0; c0 < cols; c0 += pc) {
             const int nc = std::min(pc, cols - c0);
-            HIPC(hipMemcpy2DAsync(buf, sizeof(double) * (size_t)rows, h + (int64_t)c0 * ldh, sizeof(double) * (size_t)ldh,
-                                  sizeof(double) * (size_t)rows, (size_t)nc, hipMemcpyHostToDevice, st));
+            if (ldh == rows) fu.copy(buf, h + (int64_t)c0 * ldh, sizeof(double) * (size_t)rows * (size_t)nc);
+            else for (int c = 0; c < nc; ++c) fu.copy(buf + (int64_t)c * rows, h + (int64_t)(c0 + c) * ldh, sizeof(double) * (size_t)rows);
             import_colmajor<T>(st, buf, rows, rows, nc, d + c0, ldd);
             HIPC(hipStreamSynchronize(st));
         }
@@ -627,18 +657,23 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         if (sb_host) (void)hipHostFree(sb_host);
         if (st) (void)hipStreamDestroy(st);
     }
+    // Loading a batch: everything goes through ONE pinned ring (several host threads fill a half while the other half travels) and ONE device staging buffer,
+    // all on the handle's stream -- the copy into `stage` for matrix k + 1 is ordered behind the import kernel that read matrix k, so nothing waits on the host until
+    // finish_loading().  (A synchronisation per matrix left the DMA idle while the host copied and the host idle while the DMA ran: 64 QPs of n = 1024 took 150 ms to load.)
+    std::unique_ptr<FastUploader> loader;
     void put_vec(const double* h, T* d, int64_t cnt_) {
         if (cnt_ <= 0) return;
-        HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)cnt_, hipMemcpyHostToDevice, st));
+        if (!loader) loader.reset(new FastUploader(st, device));
+        loader->copy(stage, h, sizeof(double) * (size_t)cnt_);
         convert_copy<T>(st, stage, d, cnt_);
-        HIPC(hipStreamSynchronize(st));
     }
     void put_matrix(const double* h, int rows, int cols, T* d) {   // column-major rows x cols (ld = rows) -> row-major, ld NP
         if (rows <= 0 || cols <= 0) return;
-        HIPC(hipMemcpyAsync(stage, h, sizeof(double) * (size_t)rows * cols, hipMemcpyHostToDevice, st));
+        if (!loader) loader.reset(new FastUploader(st, device));
+        loader->copy(stage, h, sizeof(double) * (size_t)rows * cols);
         import_colmajor<T>(st, stage, rows, rows, cols, d, NP);
-        HIPC(hipStreamSynchronize(st));
     }
+    void finish_loading() { HIPC(hipStreamSynchronize(st)); loader.reset(); }
     void get_dual(double* zh, double* yh) override {
         HIPC(hipSetDevice(device));
         for (int b = 0; b < count && m > 0; ++b) {
@@ -714,6 +749,7 @@ template <typename T> struct BatchedDenseSolver : BatchSolverBase {
         have_AA = true; fac_sigma = sigma; fac_nb = nb;
         for (int b : todo) fac_rho[b] = p.rho;
         for (int b = 0; b < count; ++b) put_vec(xh + (int64_t)b * n, x + (int64_t)b * NP, n);
+        loader.reset();                                                                             // (gives the pinned ring back)
         HIPC(hipMemsetAsync(z, 0, sizeof(T) * (size_t)count * MP, st));                             // :39
         HIPC(hipMemsetAsync(y, 0, sizeof(T) * (size_t)count * MP, st));                             // :40
         push_state(rho, rhorho, active);
@@ -880,25 +916,58 @@ int fail_with(Handle* h, int code, const std::string& msg) {
     return code;
 }
 bool all_finite(const double* p, int64_t count, bool allow_inf) {
-    for (int64_t i = 0; i < count; ++i) {
-        const double v = p[i];
-        if (std::isnan(v)) return false;
-        if (!allow_inf && std::isinf(v)) return false;
-    }
-    return true;
+    // branch-free over blocks (vectorises), an early exit between blocks; large arrays on several host threads
+    std::atomic<int> bad{0};
+    host_parallel(count, (int64_t)1 << 20, [&](int, int64_t b, int64_t e) {
+        for (int64_t i0 = b; i0 < e && !bad.load(std::memory_order_relaxed); i0 += 4096) {
+            const int64_t i1 = std::min(e, i0 + 4096);
+            int flag = 0;
+            if (allow_inf) { for (int64_t i = i0; i < i1; ++i) flag |= (p[i] != p[i]); }
+            else { for (int64_t i = i0; i < i1; ++i) flag |= !(std::fabs(p[i]) <= 1.7976931348623157e308); }
+            if (flag) bad.store(1, std::memory_order_relaxed);
+        }
+    });
+    return bad.load() == 0;
+}
+// a column-major matrix (every column `rows` long, `ld` apart): contiguous storage is checked as one array
+bool all_finite_matrix(const double* p, int64_t rows, int64_t cols, int64_t ld) {
+    if (ld == rows) return all_finite(p, rows * cols, false);
+    std::atomic<int> bad{0};
+    host_parallel(cols, std::max<int64_t>(1, ((int64_t)1 << 20) / std::max<int64_t>(rows, 1)), [&](int, int64_t b, int64_t e) {
+        for (int64_t j = b; j < e && !bad.load(std::memory_order_relaxed); ++j) {
+            int flag = 0;
+            for (int64_t i = 0; i < rows; ++i) flag |= !(std::fabs(p[i + j * ld]) <= 1.7976931348623157e308);
+            if (flag) bad.store(1, std::memory_order_relaxed);
+        }
+    });
+    return bad.load() == 0;
 }
 // issymmetric(mP) with tolerance 0, as SolveQuadraticProgram.m:166-168 (the MATLAB implementation raises; the CSR path reads the
 // caller's CSC of P as its CSR and the dense check reads rows of P, so an asymmetric P would silently solve a different problem).
 // Tiled so that both the (i, j) and the (j, i) walk stay inside a cached 64 x 64 block.  Returns -1 or the first offending column.
 int64_t dense_asymmetry(const double* P, int64_t n, int64_t ldp) {
-    for (int64_t j0 = 0; j0 < n; j0 += 64)
-        for (int64_t i0 = j0; i0 < n; i0 += 64) {
-            const int64_t j1 = std::min(n, j0 + 64), i1 = std::min(n, i0 + 64);
-            for (int64_t j = j0; j < j1; ++j)
-                for (int64_t i = std::max(i0, j + 1); i < i1; ++i)
-                    if (P[i + j * ldp] != P[j + i * ldp]) return j;
+    const int64_t nb = (n + 63) / 64;
+    std::atomic<int64_t> first{INT64_MAX};
+    // block columns dealt cyclically over the host threads (block column b holds nb - b tiles); the smallest offending column wins, as in a serial sweep
+    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n * n / ((int64_t)1 << 20)));
+    auto work = [&](int t) {
+        for (int64_t b = t; b < nb; b += nt) {
+            const int64_t j0 = b * 64;
+            if (j0 >= first.load(std::memory_order_relaxed)) break;
+            for (int64_t i0 = j0; i0 < n; i0 += 64) {
+                const int64_t j1 = std::min(n, j0 + 64), i1 = std::min(n, i0 + 64);
+                for (int64_t j = j0; j < j1; ++j)
+                    for (int64_t i = std::max(i0, j + 1); i < i1; ++i)
+                        if (P[i + j * ldp] != P[j + i * ldp]) { int64_t cur = first.load(); while (j < cur && !first.compare_exchange_weak(cur, j)) {} }
+            }
         }
-    return -1;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    const int64_t f = first.load();
+    return f == INT64_MAX ? -1 : f;
 }
 int check_device(int device) {
     int cnt = 0;
@@ -979,8 +1048,8 @@ QPS_API int32_t qps_create_dense(int64_t n, int64_t m, const double* P, int64_t 
     if (!P || !q || (m > 0 && (!A || !l || !u))) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "NULL problem array");
     if (ldp < n || (m > 0 && lda < m)) return fail_with(nullptr, QPS_ERR_BAD_DIMENSION, "leading dimension smaller than the row count");
     if (dtype != QPS_F64 && dtype != QPS_F32) return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, "unknown dtype");
-    for (int64_t j = 0; j < n; ++j) if (!all_finite(P + j * ldp, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P contains NaN/Inf");
-    for (int64_t j = 0; j < n && m > 0; ++j) if (!all_finite(A + j * lda, m, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "A contains NaN/Inf");
+    if (!all_finite_matrix(P, n, n, ldp)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P contains NaN/Inf");
+    if (m > 0 && !all_finite_matrix(A, m, n, lda)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "A contains NaN/Inf");
     if (!all_finite(q, n, false)) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "q contains NaN/Inf");
     if (m > 0 && (!all_finite(l, m, true) || !all_finite(u, m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
     {
@@ -1119,8 +1188,15 @@ QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, cons
     if (!all_finite(P, count * n * n, false) || !all_finite(q, count * n, false) || (m > 0 && !all_finite(A, count * m * n, false)))
         return fail_with(nullptr, QPS_ERR_NOT_FINITE, "P/A/q contain NaN/Inf");
     if (m > 0 && (!all_finite(l, count * m, true) || !all_finite(u, count * m, true))) return fail_with(nullptr, QPS_ERR_NOT_FINITE, "l/u contain NaN");
-    for (int64_t b = 0; b < count; ++b)
-        if (dense_asymmetry(P + b * n * n, n, n) >= 0) { char bf[160]; snprintf(bf, sizeof bf, "QP %lld of the batch: the matrix mP must be a symmetric positive definite matrix", (long long)b); return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, bf); }
+    {   // issymmetric(mP) for every QP of the batch, the QPs dealt to the host threads (64 QPs of n = 1024 took 130 ms one after the other); the first offender is reported
+        std::atomic<int64_t> first_bad{INT64_MAX};
+        host_parallel(count, std::max<int64_t>(1, ((int64_t)1 << 20) / (n * n)), [&](int, int64_t b0, int64_t b1) {
+            for (int64_t b = b0; b < b1 && b < first_bad.load(std::memory_order_relaxed); ++b)
+                if (dense_asymmetry(P + b * n * n, n, n) >= 0) { int64_t cur = first_bad.load(); while (b < cur && !first_bad.compare_exchange_weak(cur, b)) {} }
+        });
+        const int64_t b = first_bad.load();
+        if (b != INT64_MAX) { char bf[160]; snprintf(bf, sizeof bf, "QP %lld of the batch: the matrix mP must be a symmetric positive definite matrix", (long long)b); return fail_with(nullptr, QPS_ERR_BAD_ARGUMENT, bf); }
+    }
     // argument validation first (a CPU-only caller sees the same errors), the device last
     int dc = check_device(device);
     if (dc == QPS_ERR_NO_DEVICE) return fail_with(nullptr, dc, "no HIP device visible: libqps_hip has no CPU fallback");
@@ -1134,6 +1210,7 @@ QPS_API int32_t qps_create_dense_batch(int64_t count, int64_t n, int64_t m, cons
             auto load = [&](auto* s) {
                 h->fused_batch = s;
                 for (int64_t b = 0; b < count; ++b) s->load_problem((int)b, P + b * n * n, A + b * m * n, q + b * n, l + b * m, u + b * m);
+                s->finish_loading();
             };
             if (dtype == QPS_F64) load(new BatchedDenseSolver<double>(device, (int)count, n, m));
             else load(new BatchedDenseSolver<float>(device, (int)count, n, m));

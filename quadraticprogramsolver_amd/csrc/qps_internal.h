@@ -2,12 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qps.h"
@@ -116,6 +118,50 @@ struct StagedUploader {
             const size_t nb = bytes < cap ? bytes : cap;
             memcpy(pin[k], s_, nb);
             HIPC(hipMemcpyAsync(d_, pin[k], nb, hipMemcpyHostToDevice, st));
+            HIPC(hipEventRecord(ev[k], st)); busy[k] = true;
+            s_ += nb; d_ += nb; bytes -= nb;
+        }
+    }
+};
+
+// ---- the boundary's host-buffer hand-over (qps_create_*): large pageable arrays -> device -----------------------------------------------------------------
+// hipMemcpyAsync from pageable memory moves ~3-10 GB/s (the runtime stages through its own small pinned buffers on one thread): at BASELINE's headline size the
+// hand-over of P and A (0.4 GB) plus their validation took 145 ms, against 64 ms for the whole solve to eps.  Here several host threads copy slices of the source
+// into a per-device pinned ring (two halves, cached per device like streams are) and every half travels as ONE hipMemcpyAsync on the handle's stream while the
+// threads fill the other half.
+int host_threads();                                                            // QPS_HOST_THREADS, default min(8, hardware threads)
+// f(t, begin, end) on `parts` slices of [0, count) run on host threads (the calling thread takes the first slice); small jobs stay on the caller
+template <typename F> inline void host_parallel(int64_t count, int64_t min_per_thread, F&& f) {
+    int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, count / std::max<int64_t>(1, min_per_thread)));
+    if (nt <= 1) { f(0, (int64_t)0, count); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (count + nt - 1) / nt;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { f(t, std::min(count, t * per), std::min(count, (t + 1) * per)); });
+    f(0, (int64_t)0, std::min(count, per));
+    for (auto& x : th) x.join();
+}
+struct PinnedRing { char* base = nullptr; size_t half = 0; };
+PinnedRing acquire_ring(int device);                                           // a cached 2 x 32 MiB pinned block (allocated on first use)
+void recycle_ring(int device, PinnedRing r);
+struct FastUploader {
+    hipStream_t st; int device; PinnedRing ring; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int cur = 0;
+    FastUploader(hipStream_t s, int dev) : st(s), device(dev) { ring = acquire_ring(dev); }
+    FastUploader(const FastUploader&) = delete;
+    ~FastUploader() {
+        for (int k = 0; k < 2; ++k) { if (busy[k]) (void)hipEventSynchronize(ev[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+        recycle_ring(device, ring);
+    }
+    // contiguous bytes; returns when the last slice has been handed to the stream (the source may then be freed: every byte sits in pinned memory or on the device)
+    void copy(void* dst, const void* src, size_t bytes) {
+        const char* s_ = static_cast<const char*>(src); char* d_ = static_cast<char*>(dst);
+        while (bytes > 0) {
+            const int k = cur; cur ^= 1;
+            if (!ev[k]) HIPC(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+            if (busy[k]) { HIPC(hipEventSynchronize(ev[k])); busy[k] = false; }
+            const size_t nb = std::min(bytes, ring.half);
+            char* pin = ring.base + (size_t)k * ring.half;
+            host_parallel((int64_t)nb, (int64_t)2 << 20, [&](int, int64_t b, int64_t e) { if (e > b) memcpy(pin + b, s_ + b, (size_t)(e - b)); });
+            HIPC(hipMemcpyAsync(d_, pin, nb, hipMemcpyHostToDevice, st));
             HIPC(hipEventRecord(ev[k], st)); busy[k] = true;
             s_ += nb; d_ += nb; bytes -= nb;
         }
