@@ -279,7 +279,9 @@ template <typename T> struct DenseSolver : SolverBase {
         ++num_factorizations;
         if (f != 0) {
             factor_valid = false;
-            char b[256]; snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A broke down: non-positive pivot at column %d (rho=%g, sigma=%g; factorisation #%d of this handle)", f, rho, sigma, num_factorizations);
+            char b[256];
+            if (f < 0) snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A: the diagonal workgroup of a fused update launch gave up waiting for its two tiles (k_chol_update_diag; rho=%g, factorisation #%d of this handle)", rho, num_factorizations);
+            else snprintf(b, sizeof b, "Cholesky of P + sigma I + rho A'A broke down: non-positive pivot at column %d (rho=%g, sigma=%g; factorisation #%d of this handle)", f, rho, sigma, num_factorizations);
             throw QpsError(QPS_ERR_FACTORIZATION, b);
         }
         factor_valid = true; fac_rho = rho; fac_sigma = sigma; fac_nb = nb; fac_premul = use_blocked();
@@ -963,8 +965,10 @@ int64_t dense_asymmetry(const double* P, int64_t n, int64_t ldp) {
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    int started = 1;
+    try { for (int t = 1; t < nt; ++t) { th.emplace_back(work, t); started = t + 1; } } catch (const std::system_error&) {}
     work(0);
+    for (int t = started; t < nt; ++t) work(t);        // (thread creation refused: the caller takes those block columns)
     for (auto& x : th) x.join();
     const int64_t f = first.load();
     return f == INT64_MAX ? -1 : f;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -136,8 +137,11 @@ template <typename F> inline void host_parallel(int64_t count, int64_t min_per_t
     if (nt <= 1) { f(0, (int64_t)0, count); return; }
     std::vector<std::thread> th;
     const int64_t per = (count + nt - 1) / nt;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { f(t, std::min(count, t * per), std::min(count, (t + 1) * per)); });
+    int started = 1;                                     // slices [started, nt) that found no thread are run by the caller (thread creation may be refused)
+    try { for (int t = 1; t < nt; ++t) { th.emplace_back([&, t] { f(t, std::min(count, t * per), std::min(count, (t + 1) * per)); }); started = t + 1; } }
+    catch (const std::system_error&) {}
     f(0, (int64_t)0, std::min(count, per));
+    for (int t = started; t < nt; ++t) f(t, std::min(count, t * per), std::min(count, (t + 1) * per));
     for (auto& x : th) x.join();
 }
 struct PinnedRing { char* base = nullptr; size_t half = 0; };
