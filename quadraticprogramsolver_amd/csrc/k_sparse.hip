@@ -784,8 +784,12 @@ template <typename T> struct SparseSolver : SolverBase {
     void upload_csr(Csr& M, const layout::CsrHost& H, bool with_src = false) {
         M.nrows = H.nrows; M.nnz = (int64_t)H.ci.size();
         {   // LDS-resident x pays once the gathers dominate; QPS_SPMV_BLOCKED = 1 / 0 forces the choice
+            // ... and only while the per-block partial sums (one per row and column block, written by the product and read back by its combine launch) stay below
+            // the matrix itself: a long banded matrix (n = 400 000: 56 column blocks) has 2.7 partial sums per entry -- 165 us per product where the CSR-stream
+            // kernel, whose gathers of x stay inside the band and hit the cache, needs a third of that
             const char* e = getenv("QPS_SPMV_BLOCKED");
-            const bool want = e ? atoi(e) != 0 : M.nnz >= 200000;
+            const int64_t nblk_ = (H.ncols + BlkOf<T>::CB - 1) / BlkOf<T>::CB;
+            const bool want = e ? atoi(e) != 0 : (M.nnz >= 200000 && nblk_ * (int64_t)H.nrows <= M.nnz);
             if (want && H.nrows > 0 && H.ncols > 0) build_blocked(M, H, with_src);
         }
         M.rp = upload_array(H.rp); M.ci = upload_array(H.ci);

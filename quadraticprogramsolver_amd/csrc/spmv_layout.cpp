@@ -296,8 +296,15 @@ template <typename T> void build_tasks(const CsrHost& M, int wgs, TaskLayout<T>&
                 ++w_;
             }
     }
-    int maxt = 1; for (int b = 0; b < nblk; ++b) maxt = std::max(maxt, out.task_ptr[(size_t)b + 1] - out.task_ptr[(size_t)b]);
-    out.wpb = std::max(1, std::min(maxt, (std::max(1, wgs) + nblk - 1) / nblk));   // about two workgroups per CU over the launch
+    // workgroups per block: enough for the tasks AND for the long rows (dealt round-robin over the block's workgroups behind the tasks) -- a block whose rows are
+    // all longer than a task (a dense-ish matrix: isotonic regression's P at n = 3000 is 3000 rows of 3000 entries) has no task at all, and one workgroup walking
+    // its 3000 rows one after the other took 15 ms per product
+    int maxt = 1, maxu = 1;
+    for (int b = 0; b < nblk; ++b) {
+        const int nt_b = out.task_ptr[(size_t)b + 1] - out.task_ptr[(size_t)b], nl_b = out.lr_ptr[(size_t)b + 1] - out.lr_ptr[(size_t)b];
+        maxt = std::max(maxt, nt_b); maxu = std::max(maxu, nt_b + nl_b);
+    }
+    out.wpb = std::max(1, std::min(maxu, (std::max(1, wgs) + nblk - 1) / nblk));   // about two workgroups per CU over the launch
     out.wpb = std::max(out.wpb, (maxt + BMAXT - 1) / BMAXT);        // at most BMAXT tasks per workgroup
     out.per = (maxt + out.wpb - 1) / out.wpb;
 }

@@ -116,6 +116,11 @@ def test_moderately_dense_matrix_goes_to_the_task_form(shim):
     check_product(shim, A, rng, tag, expect_sell=False)
     B = sp.lil_matrix(A); B[5, :] = rng.standard_normal(15000)
     check_product(shim, sp.csr_matrix(B), rng, tag + " +dense_row", expect_sell=False)
+    # a matrix whose rows are ALL longer than a task (no task at all, long rows only): the block must still get workgroups for them (stats[6] = workgroups per block)
+    D = sp.csr_matrix(rng.standard_normal((300, 2500)))
+    rc, y, stats = apply(shim, "tasks", "f64", D, np.ones(2500))
+    assert rc == 1 and stats[0] == 0 and stats[3] == 300 and stats[6] >= 256, stats
+    check_product(shim, D, rng, "dense 300 x 2500: long rows only", expect_sell=False)
     # ... while a few long rows in an otherwise sparse matrix stay in the sliced form (SLONG path of k_spmv_sell)
     S, tag2 = draw_case(rng, n=15000, m=4100, avg=8.0, dense_row=True, dense_cols=False, empty_run=True)
     check_product(shim, S, rng, tag2, expect_sell=True)
