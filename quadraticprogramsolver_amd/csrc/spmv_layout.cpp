@@ -122,6 +122,9 @@ std::vector<int> stream_row_blocks(const CsrHost& M) {
     std::vector<int> rb(1, 0);
     int start = 0;
     for (int r = 0; r < M.nrows; ++r) {
+        // ... and at most STREAM_ROWS rows: the workgroup walks its rows 32 at a time, and a block of thousands of EMPTY rows (the zero block of a lasso / Huber P:
+        // 20 100 of 30 100 rows) kept one workgroup looping for ~200 us per product
+        if (r - start >= STREAM_ROWS) { rb.push_back(r); start = r; }
         if (M.rp[(size_t)r + 1] - M.rp[(size_t)start] > STREAM_NNZ && r > start) { rb.push_back(r); start = r; }
         if (M.rp[(size_t)r + 1] - M.rp[(size_t)start] > STREAM_NNZ) { rb.push_back(r + 1); start = r + 1; }   // single long row
     }

@@ -17,6 +17,7 @@ struct Int4 { int x, y, z, w; };                 // layout-compatible with HIP's
 
 // ---- shared constants of the builders and the kernels -------------------------------------------------------------------------------
 constexpr int STREAM_NNZ = 1024;                 // k_spmv_stream: non-zeros per workgroup (256 threads x 4)
+constexpr int STREAM_ROWS = 256;                 // k_spmv_stream: rows per workgroup at most (eight passes of 32 rows)
 constexpr int X_BLOCK_BYTES = 57344;             // column-blocked forms: 56 KiB of x per block in LDS (+ 16 KiB of products: two workgroups per CU)
 constexpr int BCHUNK = 2048;                     // k_spmv_blk: non-zeros per task (512 threads x 4)
 constexpr int BTHREADS = 512;
@@ -44,7 +45,7 @@ void csc_to_csr_pair(int64_t nrows, int64_t ncols, const std::vector<int64_t>& c
 CsrHost csc_as_transposed_csr(int64_t nrows, int64_t ncols, const std::vector<int64_t>& cp, const std::vector<int64_t>& ri, const std::vector<double>& nz);
 // [top; bottom] stacked (same column count)
 CsrHost stack_rows(const CsrHost& top, const CsrHost& bottom);
-// k_spmv_stream: consecutive rows holding <= STREAM_NNZ non-zeros per workgroup; a longer row stands alone.  Returns the row-block boundaries.
+// k_spmv_stream: consecutive rows (at most STREAM_ROWS) holding <= STREAM_NNZ non-zeros per workgroup; a longer row stands alone.  Returns the row-block boundaries.
 std::vector<int> stream_row_blocks(const CsrHost& M);
 
 // ---- sliced form (k_spmv_sell) -------------------------------------------------------------------------------------------------------------
