@@ -23,6 +23,7 @@ if [ $PART = trace ]; then
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$n -o bench -- python3 $R/bench.py $a --no-cpu-baseline --no-time-to-eps --no-side-configs > $R/$O/prof_$n.log 2>&1
     rc=$?; cd $R; [ $rc -ge 124 ] && { echo "trace $n timed out: stopping"; exit 1; }
     # the per-dispatch trace summarised by tests/tools/trace_stats_split.py (one row per grid of a kernel, done-flag no-ops apart) instead of rocprofv3's own --stats table
+    r=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$r" ] && cp $r $O/bench_${n}_kernel_stats_rocprofv3_raw.csv   # rocprofv3's own --stats table, kept beside the split one
     t=$(find $O/prof_$n -name "*kernel_trace.csv" | head -1)
     [ -n "$t" ] && python tests/tools/trace_stats_split.py $t $O/bench_${n}_kernel_stats.csv && python tests/tools/stats_meta.py $O/bench_${n}_kernel_stats.csv "rocprofv3 --kernel-trace --stats --output-format csv -- $cmd ; tests/tools/trace_stats_split.py" && echo "== $n" && python tests/tools/print_stats.py $O/bench_${n}_kernel_stats.csv 6
     rm -rf $O/prof_$n
