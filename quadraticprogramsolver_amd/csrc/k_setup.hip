@@ -65,13 +65,21 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
     // opA(i0.., k0..) goes to As[k][i], opB(k0.., j0..) to Bs[k][j], 4 elements per thread each.  The slabs of the next GemmDepth k-steps are
     // in flight (in registers) while the current one is multiplied.
     T ga[GemmDepth<T>::v][4], gb[GemmDepth<T>::v][4];
+    // Addresses: everything that changes from slab to slab (k0, the row group r) is workgroup-uniform and stays in scalar registers; a thread adds only its own
+    // constant 32-bit offset.  (With the whole index formed per thread, the slabs of an operand that is NOT k-contiguous cost a 64-bit multiply per load: 97 vector
+    // instructions beside 32 MFMAs in the loop of the A'A product -- measured 41 % MFMA-pipe busy, 71 % of the wave cycles in issue stalls:
+    // profiles/r04_n_gemm_f32_counters_before.txt.)
+    const int toA = AK ? (tid >> 4) * (int)lda + (tid & 15) : (tid >> 6) * (int)lda + (tid & 63);
+    const int toB = BK ? (tid >> 4) * (int)ldb + (tid & 15) : (tid >> 6) * (int)ldb + (tid & 63);
+    const T* const uA = AK ? A + (int64_t)i0 * lda : A + i0;                      // (uniform)
+    const T* const uB = BK ? B + (int64_t)j0 * ldb : B + j0;
     auto gload = [&](T (&xa)[4], T (&xb)[4], int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; xa[r] = A[(int64_t)(i0 + i) * lda + k0 + k]; }
-            else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  xa[r] = A[(int64_t)(k0 + k) * lda + i0 + i]; }
-            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; xb[r] = B[(int64_t)(j0 + j) * ldb + k0 + k]; }
-            else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  xb[r] = B[(int64_t)(k0 + k) * ldb + j0 + j]; }
+            const T* sa = AK ? uA + (int64_t)(16 * r) * lda + k0 : uA + (int64_t)(k0 + 4 * r) * lda;     // (uniform: scalar arithmetic)
+            const T* sb = BK ? uB + (int64_t)(16 * r) * ldb + k0 : uB + (int64_t)(k0 + 4 * r) * ldb;
+            xa[r] = sa[toA];
+            xb[r] = sb[toB];
         }
     };
     // the C tile of an accumulating product is fetched first, not after the last multiply (older than every slab load: the conditional
@@ -93,12 +101,20 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
 #pragma unroll
     for (int s = 0; s < GemmDepth<T>::v; ++s) gload(ga[s], gb[s], min(kbeg + s * GK, klast));
     int buf = 0;
+    // LDS layout of a slab: an operand that is NOT k-contiguous in memory keeps [k][i] (row stride GLD = 80: stores of 64 consecutive i and the fragment reads of
+    // 16 i x 4 k are both conflict free).  A k-contiguous operand is stored the way it is loaded, [i][k] with row stride SK = 16 + 4 words (fp64: + 2 double words):
+    // its stores (16 consecutive k of four rows per wave) and its fragment reads (address (row cl) SK + k, cl SK mod 64 = sixteen distinct multiples of 4) are conflict
+    // free too -- in the [k][i] layout the stores of such an operand hit four banks sixteen lanes deep (counters: 54-70 % of the LDS cycles were bank conflicts).
+    constexpr int SK = GK + (sizeof(T) == 4 ? 4 : 2);
+    static_assert(64 * SK <= GK * GLD, "the transposed slab fits the staging buffer");
     auto step = [&](T (&xa)[4], T (&xb)[4], int kc) {
+        T* const At_ = &As[buf][0][0];
+        T* const Bt_ = &Bs[buf][0][0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; As[buf][k][i] = xa[r]; }
+            if (AK) { const int k = tid & 15, i = (tid >> 4) + 16 * r; At_[i * SK + k] = xa[r]; }
             else    { const int i = tid & 63, k = (tid >> 6) + 4 * r;  As[buf][k][i] = xa[r]; }
-            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bs[buf][k][j] = xb[r]; }
+            if (BK) { const int k = tid & 15, j = (tid >> 4) + 16 * r; Bt_[j * SK + k] = xb[r]; }
             else    { const int j = tid & 63, k = (tid >> 6) + 4 * r;  Bs[buf][k][j] = xb[r]; }
         }
         __syncthreads();   // also orders this step's reads of `buf` after the stores above, and the stores of step k+2 into `buf` after them
@@ -106,8 +122,8 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
             const int kr = kk + (lane >> 4), cl = lane & 15;
-            const T a0 = As[buf][kr][wm * 32 + cl], a1 = As[buf][kr][wm * 32 + 16 + cl];
-            const T b0 = Bs[buf][kr][wn * 32 + cl], b1 = Bs[buf][kr][wn * 32 + 16 + cl];
+            const T a0 = AK ? At_[(wm * 32 + cl) * SK + kr] : As[buf][kr][wm * 32 + cl], a1 = AK ? At_[(wm * 32 + 16 + cl) * SK + kr] : As[buf][kr][wm * 32 + 16 + cl];
+            const T b0 = BK ? Bt_[(wn * 32 + cl) * SK + kr] : Bs[buf][kr][wn * 32 + cl], b1 = BK ? Bt_[(wn * 32 + 16 + cl) * SK + kr] : Bs[buf][kr][wn * 32 + 16 + cl];
             acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
             acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
             acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
@@ -143,13 +159,22 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
 template <typename T, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                               int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
-                                              int64_t sA, int64_t sB, int64_t sC, int ktri) {
+                                              int64_t sA, int64_t sB, int64_t sC, int ktri, int pair) {
     const int bj = blockIdx.x, bi = blockIdx.y;
     if (lower_only && bj > bi) return;
     A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
     __shared__ T As[2][GK][GLD];
     __shared__ T Bs[2][GK][GLD];
     gemm_tile<T, AK, BK>(K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bi, bj, As, Bs, nullptr);
+    if constexpr (!(AK && BK)) if (pair) {   // (no triangular-operand product of this library has both operands k-contiguous: that instantiation keeps its registers)
+        // A triangular operand makes the depth of a tile grow along one axis of the tile grid (ktri 1: from K - 64 j down to 64; ktri 2 / 3: along i).  With one tile
+        // per workgroup and the whole grid resident at once, the launch lasted as long as its deepest tiles -- the 2048^3 products of the inverse doubling took as long
+        // as the FULL product although half their depth is skipped.  Here a workgroup takes a tile and its mirror image along that axis: every workgroup has the
+        // same depth in total.
+        __syncthreads();                                                           // the staging buffers are reused
+        if (ktri == 1) gemm_tile<T, AK, BK>(K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bi, 2 * (int)gridDim.x - 1 - bj, As, Bs, nullptr);
+        else gemm_tile<T, AK, BK>(K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, 2 * (int)gridDim.y - 1 - bi, bj, As, Bs, nullptr);
+    }
 }
 
 // column-major double src (rows x cols) -> row-major T dst (ld ldd), via a 64 x 64 LDS transpose tile; dst padding is
@@ -918,12 +943,18 @@ template <typename T>
 void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda, bool ak, const T* B, int64_t ldb, bool bk,
           T beta, T* C, int64_t ldc, bool lower_only, int batch, int64_t sA, int64_t sB, int64_t sC, int ktri) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
-    dim3 grid(N / GT, M / GT, batch), block(256);
     const int lo = lower_only ? 1 : 0;
-    if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
-    else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
-    else if (!ak && bk) hipLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
-    else hipLaunchKernelGGL((k_gemm<T, false, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri);
+    // triangular operand: pair every tile with its mirror image along the axis its depth varies on (see k_gemm) when that axis has an even number of tiles and the
+    // halved grid still gives every CU work
+    static const bool pair_ok = [] { const char* e = getenv("QPS_GEMM_PAIR"); return !(e && atoi(e) == 0); }();
+    const int nj = N / GT, ni = M / GT;
+    int pair = 0;
+    if (pair_ok && !lower_only && ktri != 0 && !(ak && bk) && (int64_t)ni * nj * batch >= 512) pair = (ktri == 1) ? (nj % 2 == 0) : (ni % 2 == 0);
+    dim3 grid(pair && ktri == 1 ? nj / 2 : nj, pair && ktri != 1 ? ni / 2 : ni, batch), block(256);
+    if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
+    else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
+    else if (!ak && bk) hipLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
+    else hipLaunchKernelGGL((k_gemm<T, false, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
 }
 
 template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T sigma, T* PI, int batch) {
