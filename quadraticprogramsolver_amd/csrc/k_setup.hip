@@ -156,12 +156,34 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
                 else *cp = v;
             }
 }
+// Lower tiles of an nt x nt tile grid on a 1-D grid of `nids` workgroup ids (lower_only >= 2 = nt).  Workgroups are dealt round-robin over the 8 XCDs, each with
+// an L2 of its own, and the ~64-96 tiles an XCD works on at one time are the ones whose operand panels it can share.  On the plain 2-D grid (upper tiles
+// returning at once) an XCD's tiles are every eighth of a tile row: in the short rows at the top of the triangle ~96 resident tiles span ~40 row panels and 5
+// column panels -- every panel byte is used by two tiles (A'A, n = 4096: L2 hit rate 48 %, 4.7 GB fetched for a 134 MB operand,
+// profiles/r04_n_gemm_f32_counters_after.txt).  Here XCD x takes the x-th eighth of the tiles in an order that walks the triangle in 8 x 8 super-blocks (row-major
+// inside a block, blocks row-major inside the triangle): 64 consecutive tiles share 16 panels.  A'A 4096 x 4096 x 8192: 1.80 -> 1.39 ms fp32 (99 TFLOP/s), 3.39 -> 2.61 ms fp64.
+__device__ __forceinline__ bool lower_tile_of(int id, int nids, int nt, int& bi, int& bj) {
+    constexpr int S = 8;                                                           // (4 ... 16 measure the same: profiles/r04_o_gemm_lower_map.log)
+    int t = (id & 7) * (nids >> 3) + (id >> 3);
+    const int nsb = (nt + S - 1) / S;
+    for (int I = 0; I < nsb; ++I) {
+        const int rows = min(S, nt - I * S), full = rows * I * S, cnt = full + rows * (rows + 1) / 2;
+        if (t < cnt) {
+            if (t < full) { const int J = t / (rows * S), r = t - J * rows * S; bi = I * S + r / S; bj = J * S + r % S; }
+            else { int r = t - full, a = 0; while (r > a) { r -= a + 1; ++a; } bi = I * S + a; bj = I * S + r; }
+            return true;
+        }
+        t -= cnt;
+    }
+    return false;                                                                  // padding ids of the last XCD
+}
 template <typename T, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                               int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
                                               int64_t sA, int64_t sB, int64_t sC, int ktri, int pair) {
-    const int bj = blockIdx.x, bi = blockIdx.y;
-    if (lower_only && bj > bi) return;
+    int bj = blockIdx.x, bi = blockIdx.y;
+    if (lower_only >= 2) { if (!lower_tile_of((int)blockIdx.x, (int)gridDim.x, lower_only, bi, bj)) return; }
+    else if (lower_only && bj > bi) return;
     A += (int64_t)blockIdx.z * sA; B += (int64_t)blockIdx.z * sB; C += (int64_t)blockIdx.z * sC;
     __shared__ T As[2][GK][GLD];
     __shared__ T Bs[2][GK][GLD];
@@ -252,30 +274,48 @@ __device__ long long g_potrf_clock[16];
 #define CHOL_T(k) do { } while (0)
 #define POTRF_T(k) do { } while (0)
 #endif
+// 1/d to working precision (hardware estimate + Newton steps on the FMA pipe)
+__device__ __forceinline__ double recip_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float recip_nr(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+// One column of a 16-column panel, lane = row.  The 64 columns of a diagonal block are ONE chain of dependent instructions, so what counts is the length of the
+// chain from one pivot to the next: pivot d (readlane) -> 1/d -> t = u_i / d -> a[K+1] -= t u_{K+1} -> next pivot.  The rank-1 update works on the UNSCALED
+// column u (its broadcasts do not wait for the pivot's reciprocal) and the scaling l_ik = u_i / sqrt(d) is computed beside the chain, not on it (the scaled
+// column is only needed when the panel is published).  A pivot that is not positive is recorded without a branch (`bad`: first offending column + 1; the
+// columns after it are then garbage, and the caller reports the failure).
 template <typename T, int P, int K> struct PotrfCol {
-    static __device__ __forceinline__ void run(T (&a)[16], int i, int col0, int* fail) {
-        T d = lane_bcast<16 * P + K>(a[K]);
-        if (!(d > T(0))) { if (i == 0 && fail) atomicCAS(fail, 0, col0 + 16 * P + K + 1); d = T(1); }
-        const T rs = rsqrt_nr(d);
-        a[K] *= rs;                                          // l_ik for i >= k (row k itself: d * rs = sqrt(d))
-        PotrfCol<T, P, K>::template update<K + 1>(a);
-        PotrfCol<T, P, K + 1>::run(a, i, col0, fail);
+    static __device__ __forceinline__ void run(T (&a)[16], int col0, int& bad) {
+        const T d = lane_bcast<16 * P + K>(a[K]);
+        bad = (bad == 0 && !(d > T(0))) ? col0 + 16 * P + K + 1 : bad;
+        const T t = a[K] * recip_nr(d);
+        PotrfCol<T, P, K>::template update<K + 1>(a, t);
+        a[K] *= rsqrt_nr(d);                                 // l_ik for i >= k (row k itself: d / sqrt(d) = sqrt(d))
+        PotrfCol<T, P, K + 1>::run(a, col0, bad);
     }
-    template <int J> static __device__ __forceinline__ void update(T (&a)[16]) {
+    template <int J> static __device__ __forceinline__ void update(T (&a)[16], T t) {
         if constexpr (J < 16) {
-            const T ljk = lane_bcast<16 * P + J>(a[K]);
-            a[J] -= a[K] * ljk;
-            update<J + 1>(a);
+            const T ujk = lane_bcast<16 * P + J>(a[K]);
+            a[J] -= t * ujk;
+            update<J + 1>(a, t);
         }
     }
 };
-template <typename T, int P> struct PotrfCol<T, P, 16> { static __device__ __forceinline__ void run(T (&)[16], int, int, int*) {} };
+template <typename T, int P> struct PotrfCol<T, P, 16> { static __device__ __forceinline__ void run(T (&)[16], int, int&) {} };
 
 template <typename T, int P>
 __device__ __forceinline__ void potrf_panel(T (&a)[16], T (*Lp)[LPS], int i, int g, int col0, int* fail) {
     if (g == P) {                                            // wave-uniform
         POTRF_T(3 * P);
-        PotrfCol<T, P, 0>::run(a, i, col0, fail);
+        int bad = 0;
+        PotrfCol<T, P, 0>::run(a, col0, bad);
+        if (bad && i == 0 && fail) atomicCAS(fail, 0, bad);
         POTRF_T(3 * P + 1);
 #pragma unroll
         for (int k = 0; k < 16; ++k) Lp[i][k] = a[k];
@@ -943,7 +983,7 @@ template <typename T>
 void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda, bool ak, const T* B, int64_t ldb, bool bk,
           T beta, T* C, int64_t ldc, bool lower_only, int batch, int64_t sA, int64_t sB, int64_t sC, int ktri) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
-    const int lo = lower_only ? 1 : 0;
+    int lo = lower_only ? 1 : 0;
     // triangular operand: pair every tile with its mirror image along the axis its depth varies on (see k_gemm) when that axis has an even number of tiles and the
     // halved grid still gives every CU work
     static const bool pair_ok = [] { const char* e = getenv("QPS_GEMM_PAIR"); return !(e && atoi(e) == 0); }();
@@ -951,6 +991,12 @@ void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda,
     int pair = 0;
     if (pair_ok && !lower_only && ktri != 0 && !(ak && bk) && (int64_t)ni * nj * batch >= 512) pair = (ktri == 1) ? (nj % 2 == 0) : (ni % 2 == 0);
     dim3 grid(pair && ktri == 1 ? nj / 2 : nj, pair && ktri != 1 ? ni / 2 : ni, batch), block(256);
+    // lower tiles of a square, chip-filling tile grid: 1-D grid in the XCD-aware order of lower_tile_of (QPS_GEMM_LOWER_MAP=0: the plain 2-D grid)
+    static const bool map_ok = [] { const char* e = getenv("QPS_GEMM_LOWER_MAP"); return !(e && atoi(e) == 0); }();
+    if (map_ok && lower_only && ni == nj && (int64_t)ni * (ni + 1) / 2 >= 512) {
+        lo = ni;
+        grid = dim3(8 * ((ni * (ni + 1) / 2 + 7) / 8), 1, batch);
+    }
     if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
     else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
     else if (!ak && bk) hipLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);

@@ -653,7 +653,7 @@ def test_register_resident_single_launch_kernel(gpu, c_oracle, dtype, n, m):
 
 KNOBS = [{"QPS_GRAPH": "0"}, {"QPS_SWEEP_MODE": "0"}, {"QPS_PASS_THREADS": "1024"}, {"QPS_SWEEP_RB": "4"}, {"QPS_SWEEP_WGS": "128", "QPS_PASS_WGS": "128"},
          {"QPS_SMALL_REG": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_LDSMAT": "0"}, {"QPS_SMALL_REG": "0", "QPS_SMALL_THREADS": "256"}, {"QPS_SPMV_BLOCKED": "1", "QPS_SPMV_FUSEPA": "0", "QPS_SPMV_WGS": "96"},
-         {"QPS_CHOL_STEP": "64"}, {"QPS_CHOL_FUSED": "0"}, {"QPS_CHOL_AVOID": "1"}, {"QPS_SWEEP_WAVE": "0"}]
+         {"QPS_CHOL_STEP": "64"}, {"QPS_CHOL_FUSED": "0"}, {"QPS_CHOL_AVOID": "1"}, {"QPS_SWEEP_WAVE": "0"}, {"QPS_GEMM_PAIR": "0", "QPS_GEMM_LOWER_MAP": "0"}]
 
 
 @pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
@@ -671,6 +671,10 @@ def test_tuning_knobs_do_not_change_results(gpu, knob, tmp_path):
             P, qq, A, l, u = q.GenerateDenseBenchmarkQP(n, m, stream=7, feasible=True)
             x = np.zeros(n); q.SolveQuadraticProgramInplace(x, P, qq, A, l, u, numIterations=60, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
             out[tag] = x.tolist()
+        # n = 4096: the tile grids of the setup GEMMs are large enough for the mirror-tile pairing and the XCD-aware order of the lower tiles
+        P, qq, A, l, u = q.GenerateDenseBenchmarkQP(4096, 256, stream=11, feasible=True)
+        x = np.zeros(4096); q.SolveQuadraticProgramInplace(x, P, qq, A, l, u, numIterations=20, ϵAbs=0.0, ϵRel=0.0, ρ=0.1)
+        out["wide"] = x.tolist()
         Ps, qs, As, ls, us = q.GenerateSparseBenchmarkQP(3000, 5000, densityA=4e-3, seed=5)
         x = np.zeros(3000)
         with q.QuadraticProgram(Ps, qs, As, ls, us, linsys="cg") as prob:
