@@ -2,6 +2,7 @@
 // MFMA pipe (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32), inversion of the diagonal sweep blocks.
 // Reference: LinearSystemSolvers.jl:112-114 (mAA, mPI, mL), :127-129 (rebuild on changedRho), ProxQP.jl:175-206
 // (dense Cholesky + in-place re-factorisation precedent).
+#include "tile_order.h"
 #include "qps_kernels.h"
 #include "wave_reduce.h"
 #include <algorithm>
@@ -156,27 +157,7 @@ __device__ __forceinline__ void gemm_tile(int K, T alpha, const T* __restrict__ 
                 else *cp = v;
             }
 }
-// Lower tiles of an nt x nt tile grid on a 1-D grid of `nids` workgroup ids (lower_only >= 2 = nt).  Workgroups are dealt round-robin over the 8 XCDs, each with
-// an L2 of its own, and the ~64-96 tiles an XCD works on at one time are the ones whose operand panels it can share.  On the plain 2-D grid (upper tiles
-// returning at once) an XCD's tiles are every eighth of a tile row: in the short rows at the top of the triangle ~96 resident tiles span ~40 row panels and 5
-// column panels -- every panel byte is used by two tiles (A'A, n = 4096: L2 hit rate 48 %, 4.7 GB fetched for a 134 MB operand,
-// profiles/r04_n_gemm_f32_counters_after.txt).  Here XCD x takes the x-th eighth of the tiles in an order that walks the triangle in 8 x 8 super-blocks (row-major
-// inside a block, blocks row-major inside the triangle): 64 consecutive tiles share 16 panels.  A'A 4096 x 4096 x 8192: 1.80 -> 1.39 ms fp32 (99 TFLOP/s), 3.39 -> 2.61 ms fp64.
-__device__ __forceinline__ bool lower_tile_of(int id, int nids, int nt, int& bi, int& bj) {
-    constexpr int S = 8;                                                           // (4 ... 16 measure the same: profiles/r04_o_gemm_lower_map.log)
-    int t = (id & 7) * (nids >> 3) + (id >> 3);
-    const int nsb = (nt + S - 1) / S;
-    for (int I = 0; I < nsb; ++I) {
-        const int rows = min(S, nt - I * S), full = rows * I * S, cnt = full + rows * (rows + 1) / 2;
-        if (t < cnt) {
-            if (t < full) { const int J = t / (rows * S), r = t - J * rows * S; bi = I * S + r / S; bj = J * S + r % S; }
-            else { int r = t - full, a = 0; while (r > a) { r -= a + 1; ++a; } bi = I * S + a; bj = I * S + r; }
-            return true;
-        }
-        t -= cnt;
-    }
-    return false;                                                                  // padding ids of the last XCD
-}
+// lower_only >= 2 (= tiles per side): the lower tiles on a 1-D grid in the XCD-aware order of lower_tile_of (tile_order.h)
 template <typename T, bool AK, bool BK>
 __global__ __launch_bounds__(256) void k_gemm(int K, T alpha, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                               int64_t ldb, T beta, T* __restrict__ C, int64_t ldc, int lower_only,
@@ -231,12 +212,14 @@ __global__ void k_make_PI(int n, int NP, const T* __restrict__ P, T sigma, T* __
 template <typename T>
 __global__ void k_assemble_M(int NP, const T* __restrict__ PI, const T* __restrict__ AA, T rho, T* __restrict__ M,
                              const double* __restrict__ rho_arr) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4, i = blockIdx.y;           // four consecutive columns per thread (NP is a multiple of 64)
     if (j >= NP || j > (i | 63)) return;                                          // lower tiles incl. whole diagonal tile
     if (rho_arr) rho = (T)rho_arr[blockIdx.z];                                    // batched: every QP has its own rho
     const int64_t o = (int64_t)blockIdx.z * NP * NP + (int64_t)i * NP + j;
     // AA holds the lower tiles of A'A; inside a diagonal tile both halves are present
-    M[o] = PI[o] + rho * AA[o];                                                   // LinearSystemSolvers.jl:114 / :128
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    const v4 p = *reinterpret_cast<const v4*>(PI + o), a = *reinterpret_cast<const v4*>(AA + o);
+    *reinterpret_cast<v4*>(M + o) = p + rho * a;                                   // LinearSystemSolvers.jl:114 / :128
 }
 
 // Cholesky of one 64 x 64 diagonal block (factor only).  256 threads: lane i = row, wave g = column group of 16, so
@@ -789,13 +772,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update_diag(T* __restrict__ M, 
                        smat + (int64_t)(cbn >> 1) * 3 * 4096, fail + blockIdx.y);
         return;
     }
-    if (avoid && (L & 7) == 0) return;
-    const int t = (avoid ? L - (L >> 3) : L);                                      // 1-based index into the lower tiles behind (0, 0)
-    if (t >= g * (g + 1) / 2) return;
-    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);                    // t = bi (bi + 1) / 2 + bj, 0 <= bj <= bi
-    while (bi * (bi + 1) / 2 > t) --bi;
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    const int bj = t - bi * (bi + 1) / 2;
+    int bi, bj;
+    if (!chol_update_tile_of(L, avoid, g, bi, bj)) return;                         // (tile_order.h)
     gemm_tile<T, true, true>(K, T(-1), A21, ld, A21, ld, T(1), A22, ld, 0, bi, bj, stage[0], stage[1], nullptr);
     if (bi == 1) {                                                                 // tiles (1, 0) and (1, 1): the diagonal workgroup is waiting for them
         __threadfence();
@@ -993,9 +971,9 @@ void gemm(hipStream_t st, int M, int N, int K, T alpha, const T* A, int64_t lda,
     dim3 grid(pair && ktri == 1 ? nj / 2 : nj, pair && ktri != 1 ? ni / 2 : ni, batch), block(256);
     // lower tiles of a square, chip-filling tile grid: 1-D grid in the XCD-aware order of lower_tile_of (QPS_GEMM_LOWER_MAP=0: the plain 2-D grid)
     static const bool map_ok = [] { const char* e = getenv("QPS_GEMM_LOWER_MAP"); return !(e && atoi(e) == 0); }();
-    if (map_ok && lower_only && ni == nj && (int64_t)ni * (ni + 1) / 2 >= 512) {
+    if (map_ok && lower_only && ni == nj && ni >= 2 && (int64_t)ni * (ni + 1) / 2 * batch >= 512) {   // (batches: the ids of one QP are a multiple of 8, every QP is dealt the same way)
         lo = ni;
-        grid = dim3(8 * ((ni * (ni + 1) / 2 + 7) / 8), 1, batch);
+        grid = dim3(lower_tile_ids(ni), 1, batch);
     }
     if (ak && bk) hipLaunchKernelGGL((k_gemm<T, true, true>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
     else if (ak && !bk) hipLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, st, K, alpha, A, lda, B, ldb, beta, C, ldc, lo, sA, sB, sC, ktri, pair);
@@ -1007,7 +985,7 @@ template <typename T> void make_PI(hipStream_t st, int n, int NP, const T* P, T 
     hipLaunchKernelGGL((k_make_PI<T>), dim3((NP + 255) / 256, NP, batch), dim3(256), 0, st, n, NP, P, sigma, PI);
 }
 template <typename T> void assemble_M(hipStream_t st, int NP, const T* PI, const T* AA, T rho, T* M, int batch, const double* rho_arr) {
-    hipLaunchKernelGGL((k_assemble_M<T>), dim3((NP + 255) / 256, NP, batch), dim3(256), 0, st, NP, PI, AA, rho, M, rho_arr);
+    hipLaunchKernelGGL((k_assemble_M<T>), dim3((NP + 1023) / 1024, NP, batch), dim3(256), 0, st, NP, PI, AA, rho, M, rho_arr);
 }
 
 // batch > 1: the same factorisation for `batch` matrices NP*NP apart (dinv blocks (NP/64)*4096 apart, fail flags 1 apart):
@@ -1040,7 +1018,7 @@ template <typename T> void cholesky(hipStream_t st, int NP, T* M, T* dinv, int* 
             // a trailing GEMM that fills the chip is kept off the diagonal workgroup's XCD -- unless it is so long that 8/7 of it exceeds the contended
             // factorisation (fp64 beyond ~56 x 56 tiles: 102.7 against 94.2 us at 62 x 62)
             const int avoid = (batch == 1 && nt >= chol_avoid_tiles() && (sizeof(T) == 4 || nt <= 1500)) ? 1 : 0;
-            const int ids = 1 + nt + (avoid ? nt / 7 + 2 : 0);
+            const int ids = chol_update_ids(g, avoid);
             hipLaunchKernelGGL((k_chol_update_diag<T>), dim3(ids, batch), dim3(256), 0, st, M, (int64_t)NP, cb + 2, 128, nblk, g, avoid, dinv, scratch, roff,
                                fail_dev, sM, sD, sS);
         }

@@ -10,6 +10,7 @@
 #include "../../quadraticprogramsolver_amd/csrc/batch_schedule.h"
 #include "../../quadraticprogramsolver_amd/csrc/ldl_symbolic.h"
 #include "../../quadraticprogramsolver_amd/csrc/spmv_layout.h"
+#include "../../quadraticprogramsolver_amd/csrc/tile_order.h"
 
 using namespace qps;
 using namespace qps::layout;
@@ -130,5 +131,25 @@ SHIM_API int lt_ldl_analyze(int n, int m, const int64_t* Pcp, const int64_t* Pri
         if (report) { report[0] = s.N; report[1] = s.Ns; report[2] = s.Nt; report[3] = (int64_t)s.level_ptr.size() - 1; report[4] = s.levels_total; report[5] = s.nnzK; report[6] = s.nnzL_exact; report[7] = s.nnzL; }
         return 0;
     } catch (const std::exception&) { return -1; }
+}
+// The id -> tile maps of tile_order.h walked over a whole launch: tiles[(bi * nt + bj)] counts how often tile (bi, bj) was dealt.  kind 0: k_gemm's lower tiles of an
+// nt x nt grid (returns the number of ids of the launch, ids_per_xcd_span[x] = number of distinct tile ROWS + COLUMNS XCD x touches in its first 64 tiles);
+// kind 1 / 2: k_chol_update_diag without / with the XCD rule (id 0, the diagonal workgroup, takes tile (0, 0) itself and is not dealt).
+SHIM_API int lt_tile_order(int kind, int nt, int* tiles, int* panels_first64) {
+    const int nids = kind == 0 ? lower_tile_ids(nt) : chol_update_ids(nt, kind == 2);
+    std::vector<std::vector<char>> rows(8, std::vector<char>((size_t)nt, 0)), cols(8, std::vector<char>((size_t)nt, 0));
+    std::vector<int> dealt(8, 0);
+    for (int id = 0; id < nids; ++id) {
+        int bi = -1, bj = -1;
+        const bool got = kind == 0 ? lower_tile_of(id, nids, nt, bi, bj) : chol_update_tile_of(id, kind == 2, nt, bi, bj);
+        if (!got) continue;
+        if (bi < 0 || bi >= nt || bj < 0 || bj > bi) return -1;
+        if (kind == 2 && (id & 7) == 0) return -2;                                 // an id on the diagonal workgroup's XCD was given a tile
+        ++tiles[(size_t)bi * nt + bj];
+        const int x = id & 7;
+        if (dealt[x]++ < 64) { rows[x][(size_t)bi] = 1; cols[x][(size_t)bj] = 1; }
+    }
+    if (panels_first64) for (int x = 0; x < 8; ++x) { int c = 0; for (int k = 0; k < nt; ++k) c += rows[x][(size_t)k] + cols[x][(size_t)k]; panels_first64[x] = c; }
+    return nids;
 }
 }

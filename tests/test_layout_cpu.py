@@ -233,3 +233,26 @@ def test_ldl_symbolic_analysis_on_the_host_build(shim):
                              8192, 64, 4096, _ip64(perm), _ip64(rep))
     assert rc == 0 and sorted(perm.tolist()) == list(range(n + m))
     assert rep[0] == n + m and rep[1] + rep[2] == n + m and rep[6] >= rep[5] - (n + m)          # nnz(L) >= strictly-lower nnz(K) (diagonal aside)
+
+
+def test_tile_order_deals_every_lower_tile_exactly_once(shim):
+    """tile_order.h: the workgroup id -> tile maps of the MFMA GEMM's lower-tile launch (k_gemm, XCD-aware order) and of the Cholesky's fused trailing update
+    (k_chol_update_diag, with and without the rule that keeps ids on the diagonal workgroup's XCD idle) deal every lower tile exactly once for every grid size,
+    and the GEMM order keeps the first 64 tiles of every XCD within few operand panels (what it exists for)."""
+    shim.lt_tile_order.restype = C.c_int
+    shim.lt_tile_order.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for nt in list(range(1, 41)) + [62, 63, 64, 65, 100, 128, 256]:
+        for kind in (0, 1, 2):
+            tiles = np.zeros((nt, nt), dtype=np.int32); panels = np.zeros(8, dtype=np.int32)
+            nids = shim.lt_tile_order(kind, nt, tiles.ctypes.data, panels.ctypes.data)
+            assert nids > 0, (kind, nt, nids)
+            want = np.tril(np.ones((nt, nt), dtype=np.int32))
+            if kind != 0:
+                want[0, 0] = 0                                               # the diagonal workgroup's own tile
+            assert np.array_equal(tiles, want), (kind, nt)
+            if kind == 0:
+                assert nids % 8 == 0 and nids - nt * (nt + 1) // 2 < 8
+                if nt >= 32:
+                    # 64 consecutive tiles of the super-block order touch 8 + 8 panels per block they straddle (the plain 2-D grid: ~45 at the top of the triangle);
+                    # a ragged last super-row (nt = 33: one tile row of 33 tiles) is the exception
+                    assert np.median(panels) <= 26 and panels.max() <= 48, (nt, panels)
