@@ -22,4 +22,5 @@ for n in ("c2", "c2_trsv1024", "c5", "c3", "c4", "c1"):
     cb = f"{k(c['value'])} {c.get('unit', '')} (min {k(c.get('value_min', c['value']))}, {c.get('samples', 1)} samples)" if c else "—"
     extra = ""
     if d.get("refactor"): extra = f"; refactor {d['refactor']['ms_each']} ms each = {round(100 * d['refactor']['share_of_loop_time'])} % of the loop"
-    print(f"| {n} | **{k(d['value'])} {d['unit']}**, setup {d.get('setup_ms', '?')} ms{extra} | {dom} | {loop} | {tt} | {cb} |")
+    setup = f", setup {d['setup_ms']} ms" if d.get("setup_ms") is not None else ""
+    print(f"| {n} | **{k(d['value'])} {d['unit']}**{setup}{extra} | {dom} | {loop} | {tt} | {cb} |")
