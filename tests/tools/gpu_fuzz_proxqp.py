@@ -37,11 +37,30 @@ for c in range(cases):
             small = min(rr["PrimalResidual"], rr["DualResidual"])
             noise = max(rr["PrimalResidual"], rr["DualResidual"]) < 1e-9
             rho_tol = max(1e-8, 1e-12 / max(small, 1e-300))
-            same = rg["Converged"] == rr["Converged"] and rg["Iterations"] == rr["Iterations"] and (noise or abs(rg["ρ"] - rr["ρ"]) <= rho_tol * rr["ρ"])
-        if not (d0 <= 1e-7 and dev <= 1e-6 and same):
+            rho_dev = abs(rg["ρ"] - rr["ρ"]) / rr["ρ"]
+            same = rg["Converged"] == rr["Converged"] and rg["Iterations"] == rr["Iterations"] and (noise or rho_dev <= rho_tol)
+        note = ""
+        if d0 <= 1e-7 and rg["Iterations"] == rr["Iterations"] and not (dev <= 1e-6 and same):
+            # The final residuals do not tell whether a residual sat at rounding level at an EARLIER check (seed 23 case 95: r_d = 5e-11 at the first check, iterates
+            # equal to 8e-16 there, rho apart by 2.7e-4 from then on: profiles/r04_p_proxqp_case_trace.log).  The yardstick for such a case is the reference itself:
+            # the restatement run again on inputs moved in the last bit.  What it does to its own answer, the device may do too (x 50: one sample of a noise).
+            pr = np.random.default_rng(c)
+            jig = lambda a: a * (1.0 + (pr.integers(0, 2, size=a.shape) * 2 - 1) * 2.0 ** -52)
+            ref2 = po.ProxQP.from_problem(Pd, jig(qv), Ad, jig(b) if me else b, Cd, jig(d) if mi else d)
+            r2 = po.SolveQuadraticProgramProxQP(ref2, numIterations=K, ρ=rho, σ=1e-2, adptΡ=adpt, τ=10.0, numItrConv=nic)
+            self_dev = max(rel(ref2.vX, ref.vX), rel(ref2.vZ, ref.vZ) if mi else 0.0, rel(ref2.vS, ref.vS) if mi else 0.0)
+            self_rho = abs(r2["ρ"] - rr["ρ"]) / rr["ρ"]
+            if dev <= max(1e-6, 50 * self_dev) and rho_dev <= max(rho_tol, 50 * self_rho) and rg["Converged"] == rr["Converged"]:
+                same = True; dev_ok = True
+                note = f" [amplified rounding: the restatement moves its own answer by {self_dev:.1e} (rho {self_rho:.1e}) under a last-bit change of q, b, d]"
+            else:
+                dev_ok = dev <= 1e-6
+        else:
+            dev_ok = dev <= 1e-6
+        if not (d0 <= 1e-7 and dev_ok and same):
             bad += 1; print(f"MISMATCH {tag}: init {d0:.1e} dev {dev:.1e} report {rg} vs {rr}", flush=True)
         else:
-            print(f"ok {tag}: init {d0:.1e} dev {dev:.1e}", flush=True)
+            print(f"ok {tag}: init {d0:.1e} dev {dev:.1e}{note}", flush=True)
     except Exception as e:
         bad += 1; print(f"ERROR {tag}: {type(e).__name__}: {e}", flush=True)
 print(f"{cases} cases, {bad} bad, {time.time() - t0:.0f} s")
