@@ -380,7 +380,7 @@ using layout::SIGMA;                  // sorting window (rows), 2048.  8192 meas
                                       // way), products 27.9 / 17.1 -> 33.4 / 18.9 us -- the row sums of a slice then scatter over 64 KB of the partial sums instead of 16 KB
 using layout::SLONG;                  // more entries than this in one block: the row is summed by a wave of its own
 constexpr int SU = 4;                 // units of a slice in flight per batch (8: same time -- the launch is not bound by round trips per slice)
-struct SellDims { int nrows, ncols, nsl, wpb; };   // nsl = slices per column block
+struct SellDims { int nrows, ncols, nsl, wpb, win, nwin, staged; };   // nsl = slices per column block; win / nwin / staged: the sorting window (spmv_layout.h, SellLayout)
 template <typename T> struct SellOf;
 template <> struct SellOf<double> { static constexpr int E = layout::sell_e<double>(); using CV = unsigned; };
 template <> struct SellOf<float> { static constexpr int E = layout::sell_e<float>(); using CV = uint2; };
@@ -404,6 +404,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_sell(SellDims a, const int* _
     constexpr int VN = VecOf<T>::N, XV = CB / (BTHREADS * VN);
     __shared__ __align__(16) T xs[CB + 8];                      // xs[CB] = 0: what a padding entry is multiplied by
     __shared__ double sh[NW];
+    __shared__ T wsum[layout::WMAX];                            // staged form: the row sums of the window in progress (xs + wsum: two workgroups per CU still fit)
     const int nrows = a.nrows;
     const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: slice offsets stay scalar
     T beta = T(0);
@@ -426,8 +427,8 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_sell(SellDims a, const int* _
         beta = (T)(res2 / prev2);
     }
     const int s_begin = wg_ptr[b * (a.wpb + 1) + blockIdx.x], s_end = wg_ptr[b * (a.wpb + 1) + blockIdx.x + 1];
-    const int lr0 = lr_ptr[b], lr1 = lr_ptr[b + 1];
-    if (s_begin >= s_end && lr0 + (int)blockIdx.x * NW >= lr1) return;   // (workgroup-uniform)
+    const int lr0 = lr_ptr[b * a.nwin], lr1 = lr_ptr[(b + 1) * a.nwin];
+    if (s_begin >= s_end && (a.staged || lr0 + (int)blockIdx.x * NW >= lr1)) return;   // (workgroup-uniform)
     QPS_STAMP(0);
     const int c0 = b * CB, cw = min(CB, a.ncols - c0);
     const int64_t sb = (int64_t)b * a.nsl;
@@ -473,6 +474,61 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_sell(SellDims a, const int* _
     __syncthreads();                                            // xs complete; the only barrier of the kernel
     QPS_STAMP(2);
     T* pout = partial + (int64_t)b * nrows;
+    const int spw = a.win >> 6;                                 // slices per sorting window
+    // One slice: the lane's row sum.  (UNCONDITIONAL loads: a unit past the slice re-reads its last one and is not used)
+    auto slice_sum = [&](int s) {
+        const int u0 = sl_off[sb + s], nu = sl_off[sb + s + 1] - u0;            // (scalar loads)
+        T acc = T(0);
+        for (int ub = 0; ub < nu; ub += SU) {
+            CV cp[SU]; V vv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int64_t at = ((int64_t)(u0 + min(ub + u, nu - 1))) * 64 + lane;
+                cp[u] = cols[at]; vv[u] = vals[at];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                if (ub + u < nu) {                              // (scalar condition: no vector-memory operation behind it)
+                    int c[E]; T v[E];
+                    sell_cols(cp[u], c); sell_vals(vv[u], v);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc += v[e] * xs[c[e]];
+                }
+            }
+        }
+        return acc;
+    };
+    auto long_sum = [&](int i) {                                // a long row: one wave, every lane returns the sum
+        const int4 d = lr_desc[i];
+        T sum = T(0);
+        for (int k = d.y + lane; k < d.z; k += 64) sum += lva[k] * xs[lci[k]];
+        return wave_sum_all(sum);
+    };
+    if (a.staged) {
+        // The workgroup owns whole windows (wg_ptr boundaries are multiples of spw).  A lane's row sum goes to its row's place in wsum (LDS), the long rows of the
+        // window are summed by the same workgroup, and the window leaves as ONE contiguous run of stores.  Stored lane by lane (below), the 64 row sums of a slice are
+        // 64 partial writes of 64-byte lines scattered over the window: on BASELINE config 3 the partial sums were 40 % of the launch's L2 transactions and 2.5 x
+        // their size in HBM write traffic (profiles/r04_z_pmc_traffic_c3.txt); with stores as coalesced as these the products take 10 / 13 % less
+        // (profiles/r04_q_c3_coalesced_store_experiment.log).
+        for (int w = s_begin / spw; w * spw < s_end; ++w) {
+            const int s1 = min((w + 1) * spw, a.nsl);
+            for (int s = w * spw + wave; s < s1; s += NW) {
+                const unsigned pm = perm[(sb + s) * 64 + lane];
+                const T acc = slice_sum(s);
+                if (pm != 0xffffu) wsum[pm] = acc;
+            }
+            for (int i = lr_ptr[b * a.nwin + w] + wave; i < lr_ptr[b * a.nwin + w + 1]; i += NW) {
+                const T sum = long_sum(i);
+                if (lane == 0) wsum[lr_desc[i].x - w * a.win] = sum;
+            }
+            __syncthreads();
+            const int r0 = w * a.win, wr = min(a.win, nrows - r0);
+            for (int i = tid; i < wr; i += BTHREADS) pout[r0 + i] = wsum[i];
+            if ((w + 1) * spw < s_end) __syncthreads();         // (uniform) the next window reuses wsum
+        }
+        QPS_STAMP(63);
+        return;
+    }
     for (int s = s_begin + wave; s < s_end; s += NW) {
         const int u0 = sl_off[sb + s], nu = sl_off[sb + s + 1] - u0;            // (scalar loads)
         const unsigned pm = perm[(sb + s) * 64 + lane];
@@ -494,7 +550,7 @@ __global__ __launch_bounds__(BTHREADS) void k_spmv_sell(SellDims a, const int* _
                 }
             }
         }
-        if (pm != 0xffffu) pout[(s / (SIGMA / 64)) * SIGMA + (int)pm] = acc;    // SIGMA / 64 slices per sorting window
+        if (pm != 0xffffu) pout[(s / spw) * a.win + (int)pm] = acc;             // spw slices per sorting window
         QPS_STAMP(3 + (s - s_begin) / NW);
     }
     // long rows of this block: one wave per row
@@ -699,7 +755,7 @@ struct Csr {
     int* task_ptr = nullptr; int4* tasks = nullptr; int per = 1, lpr4 = 0; void* partial = nullptr;
     int* lr_ptr = nullptr; int4* lr_desc = nullptr;   // rows with more than BCHUNK entries in one block: (row, first entry, end entry, 0), [nblk + 1] ranges
     // sliced form (k_spmv_sell): units of 64 lanes x E entries; bci / bva then hold only the long rows' entries
-    bool sell = false; int nsl = 0; int* wg_ptr = nullptr; int* sl_off = nullptr; unsigned short* sl_perm = nullptr; void* s_cols = nullptr; void* s_vals = nullptr;
+    bool sell = false; int nsl = 0, win = layout::SIGMA, nwin = 0, staged = 0; int* wg_ptr = nullptr; int* sl_off = nullptr; unsigned short* sl_perm = nullptr; void* s_cols = nullptr; void* s_vals = nullptr;
     // value refresh of a matrix with a frozen pattern (the explicit reduced matrix): where every slot of s_vals / bva came from in `va`
     int* src = nullptr; int64_t src_n = 0; int* lsrc = nullptr; int64_t lsrc_n = 0;
 };
@@ -758,8 +814,9 @@ template <typename T> struct SparseSolver : SolverBase {
         const char* e = getenv("QPS_SPMV_SELL");                     // read per handle: 0 = the task form (k_spmv_blk)
         if (!(e && atoi(e) == 0)) {
             layout::SellLayout<T> L;
-            if (layout::build_sell<T>(H, wgs, L, with_src)) {
-                M.nblk = L.nblk; M.nsl = L.nsl; M.wpb = L.wpb;
+            const char* es = getenv("QPS_SPMV_STAGED");                 // read per handle: 0 = row sums stored lane by lane also when whole windows could be staged
+            if (layout::build_sell<T>(H, wgs, L, with_src, !(es && atoi(es) == 0))) {
+                M.nblk = L.nblk; M.nsl = L.nsl; M.wpb = L.wpb; M.win = L.win; M.nwin = L.nwin; M.staged = L.staged;
                 if (with_src) { M.src = upload_array(L.src); M.src_n = (int64_t)L.src.size(); M.lsrc = upload_array(L.lsrc); M.lsrc_n = (int64_t)L.lsrc.size(); }
                 M.s_cols = upload_array(L.cols); M.s_vals = upload_array(L.vals);
                 M.bci = upload_array(L.lci); M.bva = upload_array(L.lva);
@@ -997,7 +1054,7 @@ template <typename T> struct SparseSolver : SolverBase {
         const LaunchTiming lt = g_launch_timing;   // profiled launch: the dispatch's own begin / end timestamps (qps_kernels.h)
         g_launch_timing = LaunchTiming();
         if (M.sell) {
-            const SellDims sd{M.nrows, M.ncols, M.nsl, M.wpb};
+            const SellDims sd{M.nrows, M.ncols, M.nsl, M.wpb, M.win, M.nwin, M.staged};
             using CV = typename SellOf<T>::CV; using V = typename VecOf<T>::type;
             if (lt.start) hipExtLaunchKernelGGL((k_spmv_sell<T>), dim3(M.wpb, M.nblk), dim3(BTHREADS), 0, st, lt.start, lt.stop, 0, sd, M.wg_ptr, M.sl_off, M.sl_perm,
                                                 static_cast<const CV*>(M.s_cols), static_cast<const V*>(M.s_vals), M.bci, static_cast<const T*>(M.bva), M.lr_ptr, M.lr_desc, xin,

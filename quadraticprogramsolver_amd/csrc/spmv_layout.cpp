@@ -139,20 +139,27 @@ namespace {
 struct RowRun { int len, row, first; };           // a row's entries inside one column block: [first, first + len) of the CSR arrays
 }
 
-template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& out, bool with_src) {
+template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& out, bool with_src, bool allow_staged) {
     constexpr int CB = cb_of<T>(), E = sell_e<T>();
     const int nrows = M.nrows, ncols = M.ncols;
     const int64_t nnz = (int64_t)M.ci.size();
     if (nrows <= 0 || ncols <= 0) return false;
     const int nblk = (ncols + CB - 1) / CB;
-    const int nwin = (nrows + SIGMA - 1) / SIGMA;
-    const int nsl = (nwin - 1) * (SIGMA / 64) + ((nrows - (nwin - 1) * SIGMA) + 63) / 64;      // slices per block (only the last window is short)
+    // the sorting window: SIGMA rows, or a workgroup's share of the rows once that share is large enough to be worth staging in LDS (see SellLayout)
+    const int target = std::max(1, std::max(1, wgs) / nblk);         // workgroups per block of a launch that is resident at once
+    const int share = (nrows + target - 1) / target;
+    const bool want_staged = allow_staged && share >= 1024;
+    const int per_wg = want_staged ? (share + WMAX - 1) / WMAX : 1;   // windows per workgroup when its share exceeds the largest window: equal windows, not one full + a rest
+    const int win = want_staged ? std::min(WMAX, ((share + per_wg - 1) / per_wg + 63) / 64 * 64) : SIGMA, spw = win / 64;
+    const int nwin = (nrows + win - 1) / win;
+    const int nsl = (nwin - 1) * spw + ((nrows - (nwin - 1) * win) + 63) / 64;                 // slices per block (only the last window is short)
     if ((int64_t)nblk * nsl * 64 > 2000000000LL) return false;
     out = SellLayout<T>();
-    out.nrows = nrows; out.ncols = ncols; out.nblk = nblk; out.nsl = nsl;
+    out.nrows = nrows; out.ncols = ncols; out.nblk = nblk; out.nsl = nsl; out.win = win; out.nwin = nwin;
     out.sl_off.assign((size_t)nblk * nsl + 1, 0);
     out.perm.assign((size_t)nblk * nsl * 64, (unsigned short)0xffff);
-    out.lr_ptr.assign((size_t)nblk + 1, 0);
+    out.lr_ptr.assign((size_t)nblk * nwin + 1, 0);
+    std::vector<int64_t> wcost((size_t)nblk * nwin, 0);              // per (block, window): units + a fixed part per slice + the wave steps of its long rows
     out.cols.reserve((size_t)(nnz + nnz / 8)); out.vals.reserve((size_t)(nnz + nnz / 8));
     // the blocks are visited in order and the column indices of a row are sorted, so the entries of (block b, row r) are the run that starts
     // where the run of (b - 1, r) ended: one cursor per row instead of a table per block
@@ -162,7 +169,8 @@ template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& 
     for (int b = 0; b < nblk; ++b) {
         const int64_t cend = std::min<int64_t>((int64_t)(b + 1) * CB, ncols);
         for (int w = 0; w < nwin; ++w) {
-            const int r0 = w * SIGMA, r1 = std::min(nrows, r0 + SIGMA);
+            const int r0 = w * win, r1 = std::min(nrows, r0 + win);
+            int64_t cost = 0;
             ord.clear();
             for (int r = r0; r < r1; ++r) {
                 const int k0 = cur[(size_t)r], kend = M.rp[(size_t)r + 1];
@@ -177,6 +185,7 @@ template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& 
                         if (with_src) out.lsrc.push_back(k0 + q);
                     }
                     out.long_entries += L;
+                    cost += (L + 63) / 64 + 8;
                     if (out.lci.size() > 2000000000ULL) return false;
                     continue;
                 }
@@ -185,7 +194,7 @@ template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& 
             std::stable_sort(ord.begin(), ord.end(), [](const RowRun& x_, const RowRun& y_) { return x_.len > y_.len; });
             const int wsl = (r1 - r0 + 63) / 64;                     // slices of this window (long rows leave lanes without a row at its end)
             for (int sl = 0; sl < wsl; ++sl) {
-                const int64_t g = (int64_t)b * nsl + (int64_t)w * (SIGMA / 64) + sl;
+                const int64_t g = (int64_t)b * nsl + (int64_t)w * spw + sl;
                 out.sl_off[(size_t)g] = (int)units;
                 const int p0 = sl * 64;
                 const int L = p0 < (int)ord.size() ? ord[(size_t)p0].len : 0, nu = (L + E - 1) / E;
@@ -203,17 +212,44 @@ template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& 
                     }
                     out.entries += rr.len;
                 }
-                units += nu;
+                units += nu; cost += nu + 2;
                 if (units > 30000000LL) return false;                // int32 unit offsets x 64 lanes: leave such matrices to the task form
             }
+            out.lr_ptr[(size_t)b * nwin + w + 1] = (int)out.lr.size();
+            wcost[(size_t)b * nwin + w] = cost;
         }
-        out.lr_ptr[(size_t)b + 1] = (int)out.lr.size();
     }
     out.sl_off[(size_t)nblk * nsl] = (int)units;
     out.padded = units * 64 * E;
     // most of the matrix in long rows (a moderately dense matrix: every row holds more than SLONG entries per block): the slices would be empty
     // and lci / lva a second copy of the matrix -- the task form streams such rows in chunks of BCHUNK instead
     if (out.long_entries * 2 > nnz) return false;
+    if (want_staged) {
+        // whole windows per workgroup: contiguous window ranges of about equal cost, every workgroup at least one window; kept only if no workgroup ends up with more
+        // than 9/8 of the mean (a skewed matrix is better served by the slice-granular ranges below, whose row sums are stored lane by lane)
+        const int wpb = std::min(nwin, target);
+        std::vector<int> wg((size_t)nblk * (wpb + 1), 0);
+        bool balanced = true;
+        for (int b = 0; b < nblk && balanced; ++b) {
+            const int64_t* wc = &wcost[(size_t)b * nwin];
+            int64_t tot = 0;
+            for (int w = 0; w < nwin; ++w) tot += wc[w];
+            int* wp = &wg[(size_t)b * (wpb + 1)];
+            int k = 0; int64_t cum = 0, mine = 0, worst = 0;
+            for (int w = 0; w < nwin; ++w) {
+                cum += wc[w]; mine += wc[w];
+                const int windows_left = nwin - (w + 1), wgs_left = wpb - (k + 1);
+                if (k < wpb - 1 && (cum * wpb >= tot * (k + 1) || windows_left == wgs_left)) {
+                    wp[++k] = std::min(nsl, (w + 1) * spw); worst = std::max(worst, mine); mine = 0;
+                }
+            }
+            worst = std::max(worst, mine);
+            wp[wpb] = nsl;
+            if (worst * wpb * 8 > tot * 9 + 64 * (int64_t)wpb) balanced = false;
+        }
+        if (balanced) { out.staged = 1; out.wpb = wpb; out.wg_ptr = std::move(wg); }
+    }
+    if (!out.staged) {
     out.wpb = std::max(1, std::min(nsl, std::max(1, wgs) / nblk));  // floor: a launch of at most `wgs` workgroups is resident at once (2 per CU)
     out.wg_ptr.assign((size_t)nblk * (out.wpb + 1), 0);
     for (int b = 0; b < nblk; ++b) {                                 // slice ranges of equal cost (units + a fixed part per slice)
@@ -226,6 +262,7 @@ template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& 
             while (w < out.wpb && run_ * out.wpb >= tot * w) wp[w++] = sl + 1;
         }
         while (w <= out.wpb) wp[w++] = nsl;
+    }
     }
     out.cols.resize(out.cols.size() + 64 * E, (unsigned short)CB); out.vals.resize(out.vals.size() + 64 * E, T(0));   // a slice without units still reads one
     out.lci.resize(out.lci.size() + 64, 0); out.lva.resize(out.lva.size() + 64, T(0));
@@ -355,38 +392,59 @@ template <typename T> void apply_sell(const SellLayout<T>& L, const T* x, T* y) 
     const T nan = std::numeric_limits<T>::quiet_NaN();
     std::vector<T> partial((size_t)L.nblk * L.nrows, nan);           // NaN: a (block, row) nobody writes shows up in y
     std::vector<T> xs((size_t)CB + 8, T(0));
+    std::vector<T> wsum((size_t)WMAX);
+    const int spw = L.win / 64;
+    if (L.win % 64 != 0 || L.win > WMAX || L.nwin != (L.nrows + L.win - 1) / L.win) throw std::logic_error("apply_sell: window geometry");
+    auto put = [&](T& dst, T v) { if (dst == dst) dst = nan; else dst = v; };   // a slot written twice is poisoned: it shows up in y
+    auto slice_sums = [&](int64_t sb, int s, T* out_lane) {
+        const int u0 = L.sl_off[(size_t)(sb + s)], nu = L.sl_off[(size_t)(sb + s + 1)] - u0;
+        for (int lane = 0; lane < 64; ++lane) {
+            T acc = T(0);
+            for (int u = 0; u < nu; ++u)
+                for (int e = 0; e < E; ++e) {
+                    const size_t at = ((size_t)(u0 + u) * 64 + (size_t)lane) * E + (size_t)e;
+                    acc += L.vals.at(at) * xs.at(L.cols.at(at));
+                }
+            out_lane[lane] = acc;
+        }
+    };
+    auto long_sum = [&](int i) { const Int4 d = L.lr.at((size_t)i); T sum = T(0); for (int k = d.y; k < d.z; ++k) sum += L.lva.at((size_t)k) * xs.at(L.lci.at((size_t)k)); return sum; };
     for (int b = 0; b < L.nblk; ++b) {
         const int c0 = b * CB, cw = std::min(CB, L.ncols - c0);
         std::fill(xs.begin(), xs.end(), T(0));
         for (int c = 0; c < cw; ++c) xs[(size_t)c] = x[c0 + c];
         T* pout = &partial[(size_t)b * L.nrows];
         const int64_t sb = (int64_t)b * L.nsl;
+        T acc[64];
         for (int wg = 0; wg < L.wpb; ++wg) {                         // the slice ranges of the workgroups must tile [0, nsl)
             const int s_begin = L.wg_ptr[(size_t)b * (L.wpb + 1) + wg], s_end = L.wg_ptr[(size_t)b * (L.wpb + 1) + wg + 1];
-            for (int s = s_begin; s < s_end; ++s) {
-                const int u0 = L.sl_off[(size_t)(sb + s)], nu = L.sl_off[(size_t)(sb + s + 1)] - u0;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const unsigned pm = L.perm[(size_t)((sb + s) * 64 + lane)];
-                    T acc = T(0);
-                    for (int u = 0; u < nu; ++u)
-                        for (int e = 0; e < E; ++e) {
-                            const size_t at = ((size_t)(u0 + u) * 64 + (size_t)lane) * E + (size_t)e;
-                            acc += L.vals.at(at) * xs.at(L.cols.at(at));
-                        }
-                    if (pm != 0xffffu) {
-                        T& dst = pout[(size_t)(s / (SIGMA / 64)) * SIGMA + pm];
-                        if (dst == dst) dst = nan; else dst = acc;       // a (block, row) written twice is poisoned: it shows up in y
+            if (!L.staged) {
+                for (int s = s_begin; s < s_end; ++s) {
+                    slice_sums(sb, s, acc);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const unsigned pm = L.perm[(size_t)((sb + s) * 64 + lane)];
+                        if (pm != 0xffffu) put(pout[(size_t)(s / spw) * L.win + pm], acc[lane]);
                     }
                 }
+                continue;
+            }
+            // staged: whole windows; the window's row sums (slices, then its long rows) are collected in wsum and stored as one run
+            if (s_begin % spw != 0 || (s_end % spw != 0 && s_end != L.nsl)) throw std::logic_error("apply_sell: a staged workgroup does not own whole windows");
+            for (int w = s_begin / spw; w * spw < s_end; ++w) {
+                std::fill(wsum.begin(), wsum.end(), nan);            // a row of the window nobody sums shows up in y
+                for (int s = w * spw; s < std::min((w + 1) * spw, L.nsl); ++s) {
+                    slice_sums(sb, s, acc);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const unsigned pm = L.perm[(size_t)((sb + s) * 64 + lane)];
+                        if (pm != 0xffffu) put(wsum.at(pm), acc[lane]);
+                    }
+                }
+                for (int i = L.lr_ptr[(size_t)b * L.nwin + w]; i < L.lr_ptr[(size_t)b * L.nwin + w + 1]; ++i) put(wsum.at((size_t)(L.lr.at((size_t)i).x - w * L.win)), long_sum(i));
+                for (int r = w * L.win; r < std::min(L.nrows, (w + 1) * L.win); ++r) put(pout[(size_t)r], wsum[(size_t)(r - w * L.win)]);
             }
         }
-        for (int i = L.lr_ptr[(size_t)b]; i < L.lr_ptr[(size_t)b + 1]; ++i) {
-            const Int4 d = L.lr.at((size_t)i);
-            T sum = T(0);
-            for (int k = d.y; k < d.z; ++k) sum += L.lva.at((size_t)k) * xs.at(L.lci.at((size_t)k));
-            T& dst = pout[(size_t)d.x];
-            if (dst == dst) dst = nan; else dst = sum;
-        }
+        if (!L.staged)
+            for (int i = L.lr_ptr[(size_t)b * L.nwin]; i < L.lr_ptr[(size_t)(b + 1) * L.nwin]; ++i) put(pout[(size_t)L.lr.at((size_t)i).x], long_sum(i));
     }
     for (int r = 0; r < L.nrows; ++r) { T s = T(0); for (int b = 0; b < L.nblk; ++b) s += partial[(size_t)b * L.nrows + r]; y[r] = s; }
 }
@@ -426,8 +484,8 @@ template <typename T> void apply_tasks(const TaskLayout<T>& L, const T* x, T* y)
     for (int r = 0; r < L.nrows; ++r) { T s = T(0); for (int b = 0; b < L.nblk; ++b) s += partial[(size_t)b * L.nrows + r]; y[r] = s; }
 }
 
-template bool build_sell<double>(const CsrHost&, int, SellLayout<double>&, bool);
-template bool build_sell<float>(const CsrHost&, int, SellLayout<float>&, bool);
+template bool build_sell<double>(const CsrHost&, int, SellLayout<double>&, bool, bool);
+template bool build_sell<float>(const CsrHost&, int, SellLayout<float>&, bool, bool);
 template void build_tasks<double>(const CsrHost&, int, TaskLayout<double>&, bool);
 template void build_tasks<float>(const CsrHost&, int, TaskLayout<float>&, bool);
 template void apply_sell<double>(const SellLayout<double>&, const double*, double*);

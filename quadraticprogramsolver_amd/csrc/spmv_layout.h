@@ -24,6 +24,7 @@ constexpr int BTHREADS = 512;
 constexpr int BMAXT = 64;                        // k_spmv_blk: tasks per workgroup at most (their descriptors are staged in LDS)
 constexpr int SIGMA = 2048;                      // k_spmv_sell: sorting window (rows)
 constexpr int SLONG = 96;                        // k_spmv_sell: more entries than this in one block -> the row is summed by a wave of its own
+constexpr int WMAX = 2304;                        // k_spmv_sell: rows of a sorting window at most (staged form: the window's row sums sit in LDS, 18 KiB in fp64, before they are stored)
 template <typename T> constexpr int cb_of() { return X_BLOCK_BYTES / (int)sizeof(T); }   // columns per block
 template <typename T> constexpr int sell_e() { return sizeof(T) == 8 ? 2 : 4; }   // entries per lane and unit: one 16-byte load of values
 
@@ -53,13 +54,18 @@ std::vector<int> stream_row_blocks(const CsrHost& M);
 // of 64 (one row per lane), a slice padded to its longest row and stored unit by unit (unit u = entries u*E .. u*E+E-1 of all 64 rows, lane after
 // lane).  Padding entries carry column CB (the kernel keeps xs[CB] = 0) and value 0.  Rows with more than SLONG entries in a block are left
 // out of the slices (`lr`, their entries in lci / lva).
+// Sorting window: `win` rows (a multiple of 64; `nwin` windows per block, win / 64 slices each, the last one shorter).  Small launches keep win = SIGMA and hand
+// slices out at slice granularity (a row sum is stored by the lane that owns the row: 8-byte stores scattered over the window).  When a workgroup's share of the rows
+// reaches 1024, win is that share (<= WMAX) and -- if the windows cost about the same -- the layout is STAGED: a workgroup owns whole windows (wg_ptr boundaries are
+// multiples of win / 64), sums the long rows of its windows itself, collects a window's row sums in LDS and stores them as one contiguous run.
 template <typename T> struct SellLayout {
     int nrows = 0, ncols = 0, nblk = 0, nsl = 0, wpb = 0;    // nsl = slices per block, wpb = workgroups per block
+    int win = SIGMA, nwin = 0, staged = 0;
     std::vector<int> sl_off;                                 // [nblk * nsl + 1] first unit of a slice
     std::vector<unsigned short> perm;                        // [nblk * nsl * 64] row of a lane relative to its window (0xffff: none)
     std::vector<unsigned short> cols; std::vector<T> vals;   // unit-major, 64 lanes x E entries per unit (+ one spare unit)
     std::vector<int> wg_ptr;                                 // [nblk * (wpb + 1)] slice range of every workgroup
-    std::vector<int> lr_ptr; std::vector<Int4> lr;           // long rows per block: (row, first, end, 0) into lci / lva
+    std::vector<int> lr_ptr; std::vector<Int4> lr;           // long rows per (block, window), [nblk * nwin + 1]: (row, first, end, 0) into lci / lva
     std::vector<unsigned short> lci; std::vector<T> lva;
     std::vector<int> src, lsrc;                              // (with_src) position in the CSR arrays of every slot of vals / lva, -1 for padding
     int64_t entries = 0, padded = 0, long_entries = 0;       // statistics: stored entries, slots incl. padding, entries of long rows
@@ -67,7 +73,7 @@ template <typename T> struct SellLayout {
 // false: not representable (too many units / slices) or not worth it (most entries sit in long rows) -> use the task form
 // with_src: also record where every stored value came from, so that the values of a matrix whose pattern is fixed (the explicit reduced matrix of
 // ItrSolCg, rebuilt on every rho switch) can be refreshed on the device without rebuilding the layout
-template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& out, bool with_src = false);
+template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& out, bool with_src = false, bool allow_staged = true);
 
 // ---- task form (k_spmv_blk) ------------------------------------------------------------------------------------------------------------------
 // Per column block a CSR with 16-bit local column indices; a task = consecutive rows holding <= BCHUNK entries (<= 512 / 256 rows), every task

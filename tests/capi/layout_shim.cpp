@@ -31,7 +31,7 @@ template <typename T> int sell_apply_t(const CsrHost& H, int wgs, const double* 
     std::vector<T> xt(x, x + H.ncols), yt((size_t)H.nrows);
     apply_sell<T>(L, xt.data(), yt.data());
     for (int r = 0; r < H.nrows; ++r) y[r] = (double)yt[(size_t)r];
-    if (stats) { stats[0] = L.entries; stats[1] = L.padded; stats[2] = L.long_entries; stats[3] = (int64_t)L.lr.size(); stats[4] = L.nblk; stats[5] = L.nsl; stats[6] = L.wpb; }
+    if (stats) { stats[0] = L.entries; stats[1] = L.padded; stats[2] = L.long_entries; stats[3] = (int64_t)L.lr.size(); stats[4] = L.nblk; stats[5] = L.nsl; stats[6] = L.wpb; stats[7] = (int64_t)L.staged * 100000 + L.win; }
     return 1;
 }
 template <typename T> int tasks_apply_t(const CsrHost& H, int wgs, const double* x, double* y, int64_t* stats) {

@@ -129,3 +129,22 @@ def test_unsorted_duplicated_csc_input_at_the_c_abi(gpu):
         assert np.abs(out2 - Aref.T @ vvec).max() <= 1e-13 * scale_of(Aref.T, vvec)
     finally:
         L.qps_destroy(h)
+
+
+@pytest.mark.parametrize("staged", ["1", "0"])
+def test_staged_sliced_form_at_baseline_config_3_size(gpu, monkeypatch, staged):
+    """The staged variant of the sliced form (a workgroup owns whole sorting windows, collects their row sums in LDS and stores a window as one run; spmv_layout.h) only
+    comes into play when a workgroup's share of the rows reaches 1024 -- BASELINE config 3's size (n = 50 000, m = 100 000): every product of the operator against scipy,
+    both precisions, with a few dense rows (long rows INSIDE staged windows, summed by the window's owner) and an empty stretch of constraint rows, staged and
+    QPS_SPMV_STAGED=0 (the lane-by-lane stores) on the same matrices."""
+    monkeypatch.setenv("QPS_SPMV_STAGED", staged)                                # read per handle, at creation
+    rng = np.random.default_rng(77)
+    n, m = 50000, 100000
+    A = sp.random(m, n, density=1e-3, random_state=rng, format="lil", dtype=np.float64)
+    for r in (0, 2111, 2112, 54321, m - 1):
+        A[r, :] = sp.random(1, n, density=0.05, random_state=rng, dtype=np.float64)   # ~2500 entries: ~360 per column block (> SLONG)
+    A[60000:63000, :] = 0
+    A = sp.csc_matrix(A)
+    P = spd_companion(rng, n, 3)
+    for dtype in ("f64", "f32"):
+        check_operator(gpu, P, A, rng, f"c3-size staged={staged}", dtype, monkeypatch, "1")

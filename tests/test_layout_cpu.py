@@ -256,3 +256,42 @@ def test_tile_order_deals_every_lower_tile_exactly_once(shim):
                     # 64 consecutive tiles of the super-block order touch 8 + 8 panels per block they straddle (the plain 2-D grid: ~45 at the top of the triangle);
                     # a ragged last super-row (nt = 33: one tile row of 33 tiles) is the exception
                     assert np.median(panels) <= 26 and panels.max() <= 48, (nt, panels)
+
+
+def test_staged_sliced_form_owns_whole_windows(shim):
+    """The staged variant of the sliced form (spmv_layout.h, SellLayout): once a workgroup's share of the rows reaches 1024 the sorting window IS that share, a
+    workgroup owns whole windows, sums their long rows itself and stores a window as one run.  The interpreter walks it the way the kernel does (a window row
+    nobody sums, or summed twice, poisons y; a workgroup range that is not window-aligned raises).  Uniform matrices go staged; a matrix whose windows cost very
+    different amounts keeps the slice-granular ranges."""
+    rng = np.random.default_rng(12)
+    x = None
+    cases = []
+    # (rows, cols, density, wgs, expect staged): share = ceil(rows / (wgs // nblk))
+    for rows, cols, avg, wgs, want in ((40000, 9000, 6.0, 64, True), (52001, 20011, 4.0, 64, True), (150000, 5000, 3.0, 64, True), (9000, 9000, 6.0, 64, False)):
+        M = sp.random(rows, cols, density=avg / cols, random_state=rng, format="csr", dtype=np.float64)
+        cases.append((f"uniform {rows}x{cols}", M, wgs, want))
+    # long rows inside staged windows (dense rows: more than SLONG entries per block) and an empty stretch of rows
+    M = sp.random(40000, 8000, density=5.0 / 8000, random_state=rng, format="lil", dtype=np.float64)
+    for r in (0, 2111, 2112, 17000, 39999):
+        M[r, :] = rng.standard_normal(8000)
+    M[20000:23000, :] = 0
+    cases.append(("long rows + empty stretch", M.tocsr(), 64, None))
+    # skewed: the first tenth of the rows carries most of the entries -> windows of very different cost -> slice-granular ranges
+    top = sp.random(4000, 8000, density=80.0 / 8000, random_state=rng, format="csr", dtype=np.float64)
+    rest = sp.random(36000, 8000, density=1.0 / 8000, random_state=rng, format="csr", dtype=np.float64)
+    cases.append(("skewed", sp.vstack([top, rest]).tocsr(), 64, False))
+    for tag, M, wgs, want in cases:
+        x = rng.standard_normal(M.shape[1])
+        ref = M @ x
+        scale = (abs(M) @ np.abs(x)).max() + 1e-300
+        for dtype, tol in (("f64", 1e-13), ("f32", 2e-5)):
+            rc, y, stats = apply(shim, "sell", dtype, M, x, wgs=wgs)
+            assert rc == 1, (tag, dtype, rc)
+            staged, win = divmod(int(stats[7]), 100000)
+            assert win % 64 == 0 and 64 <= win <= 2304, (tag, win)
+            if want is not None and dtype == "f64":
+                assert bool(staged) == want, (tag, dtype, "staged" if staged else "lane-by-lane", win, stats)
+            if staged:
+                assert win >= 1024
+            assert np.all(np.isfinite(y)), (tag, dtype, "a (block, row) was written twice or never", int(np.isnan(y).sum()))
+            assert np.abs(y - ref).max() / scale <= tol, (tag, dtype)
