@@ -225,25 +225,24 @@ template <typename T> bool build_sell(const CsrHost& M, int wgs, SellLayout<T>& 
     // and lci / lva a second copy of the matrix -- the task form streams such rows in chunks of BCHUNK instead
     if (out.long_entries * 2 > nnz) return false;
     if (want_staged) {
-        // whole windows per workgroup: contiguous window ranges of about equal cost, every workgroup at least one window; kept only if no workgroup ends up with more
-        // than 9/8 of the mean (a skewed matrix is better served by the slice-granular ranges below, whose row sums are stored lane by lane)
-        const int wpb = std::min(nwin, target);
+        // whole windows per workgroup: the same number of consecutive windows each (the last workgroups may go without -- they return at once); kept only if no
+        // workgroup ends up with more than 9/8 of the mean cost (a skewed matrix is better served by the slice-granular ranges below, whose row sums are stored
+        // lane by lane).  (Balancing the window ranges by cost instead handed single workgroups a third window where two were due: with whole windows as the unit
+        // a workgroup can only be under its share, never over it, if it takes exactly its count.)
+        const int wpb = std::min(nwin, target), per = (nwin + wpb - 1) / wpb;
         std::vector<int> wg((size_t)nblk * (wpb + 1), 0);
         bool balanced = true;
         for (int b = 0; b < nblk && balanced; ++b) {
             const int64_t* wc = &wcost[(size_t)b * nwin];
-            int64_t tot = 0;
-            for (int w = 0; w < nwin; ++w) tot += wc[w];
             int* wp = &wg[(size_t)b * (wpb + 1)];
-            int k = 0; int64_t cum = 0, mine = 0, worst = 0;
-            for (int w = 0; w < nwin; ++w) {
-                cum += wc[w]; mine += wc[w];
-                const int windows_left = nwin - (w + 1), wgs_left = wpb - (k + 1);
-                if (k < wpb - 1 && (cum * wpb >= tot * (k + 1) || windows_left == wgs_left)) {
-                    wp[++k] = std::min(nsl, (w + 1) * spw); worst = std::max(worst, mine); mine = 0;
-                }
+            int64_t tot = 0, worst = 0;
+            for (int k = 0; k < wpb; ++k) {
+                const int w0 = std::min(nwin, k * per), w1 = std::min(nwin, (k + 1) * per);
+                int64_t mine = 0;
+                for (int w = w0; w < w1; ++w) mine += wc[w];
+                tot += mine; worst = std::max(worst, mine);
+                wp[k] = std::min(nsl, w0 * spw);
             }
-            worst = std::max(worst, mine);
             wp[wpb] = nsl;
             if (worst * wpb * 8 > tot * 9 + 64 * (int64_t)wpb) balanced = false;
         }
@@ -429,6 +428,7 @@ template <typename T> void apply_sell(const SellLayout<T>& L, const T* x, T* y) 
                 continue;
             }
             // staged: whole windows; the window's row sums (slices, then its long rows) are collected in wsum and stored as one run
+            if (s_begin >= s_end) continue;                                 // a workgroup without a window (the kernel returns at once)
             if (s_begin % spw != 0 || (s_end % spw != 0 && s_end != L.nsl)) throw std::logic_error("apply_sell: a staged workgroup does not own whole windows");
             for (int w = s_begin / spw; w * spw < s_end; ++w) {
                 std::fill(wsum.begin(), wsum.end(), nan);            // a row of the window nobody sums shows up in y

@@ -148,3 +148,14 @@ def test_staged_sliced_form_at_baseline_config_3_size(gpu, monkeypatch, staged):
     P = spd_companion(rng, n, 3)
     for dtype in ("f64", "f32"):
         check_operator(gpu, P, A, rng, f"c3-size staged={staged}", dtype, monkeypatch, "1")
+
+
+def test_staged_form_with_several_windows_per_workgroup(gpu, monkeypatch):
+    """A workgroup's share of the rows beyond the largest window (WMAX = 2304 rows): the share is cut into equal windows and a workgroup walks several of them, reusing
+    its LDS array behind a second barrier -- tall thin A (1.3 M x 5000: [P; A] u has 1020 windows of 1280 rows on 512 workgroups) and, transposed, a product whose 182
+    column blocks leave two workgroups per block with two windows each."""
+    rng = np.random.default_rng(78)
+    n, m = 5000, 1300000
+    A = sp.random(m, n, density=9.0 / n, random_state=rng, format="csc", dtype=np.float64)   # about as many entries per row as P: the windows of [P; A] cost the same
+    P = spd_companion(rng, n, 5)
+    check_operator(gpu, P, A, rng, "several windows per workgroup", "f64", monkeypatch, "1")

@@ -267,7 +267,7 @@ def test_staged_sliced_form_owns_whole_windows(shim):
     x = None
     cases = []
     # (rows, cols, density, wgs, expect staged): share = ceil(rows / (wgs // nblk))
-    for rows, cols, avg, wgs, want in ((40000, 9000, 6.0, 64, True), (52001, 20011, 4.0, 64, True), (150000, 5000, 3.0, 64, True), (9000, 9000, 6.0, 64, False)):
+    for rows, cols, avg, wgs, want in ((40000, 9000, 6.0, 64, True), (52001, 20011, 4.0, 64, True), (150000, 5000, 12.0, 64, True), (9000, 9000, 6.0, 64, False)):
         M = sp.random(rows, cols, density=avg / cols, random_state=rng, format="csr", dtype=np.float64)
         cases.append((f"uniform {rows}x{cols}", M, wgs, want))
     # long rows inside staged windows (dense rows: more than SLONG entries per block) and an empty stretch of rows
