@@ -131,6 +131,27 @@ def test_unsorted_duplicated_csc_input_at_the_c_abi(gpu):
         L.qps_destroy(h)
 
 
+_C3_SIZE = []
+
+
+def c3_size_matrices():
+    """(P, A) at BASELINE config 3's size, built once for both parametrisations and without scipy's lil format or a legacy RandomState (`sp.random` draws its positions
+    by permuting ALL m * n candidates with those: minutes and 20 GB at this size -- 190 of the suite's 570 s before)."""
+    if not _C3_SIZE:
+        rng = np.random.default_rng(77)
+        n, m = 50000, 100000
+        A = sp.random(m, n, density=1e-3, random_state=rng, format="csr", dtype=np.float64)
+        dense_rows = np.array([0, 2111, 2112, 54321, m - 1])
+        keep = np.ones(m); keep[60000:63000] = 0.0; keep[dense_rows] = 0.0                          # an empty stretch of constraint rows
+        R = sp.random(dense_rows.size, n, density=0.05, random_state=rng, format="csr", dtype=np.float64)   # ~2500 entries: ~360 per column block (> SLONG)
+        S = sp.csr_matrix((np.ones(dense_rows.size), (dense_rows, np.arange(dense_rows.size))), shape=(m, dense_rows.size))
+        A = (sp.diags(keep) @ A + S @ R).tocsc(); A.eliminate_zeros(); A.sort_indices()
+        M = sp.random(n, n, density=3.0 / n, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+        P = (M.T @ M + 1e-2 * sp.identity(n)).tocsc()                                               # spd_companion's recipe with a Generator
+        _C3_SIZE.append((P, A))
+    return _C3_SIZE[0]
+
+
 @pytest.mark.parametrize("staged", ["1", "0"])
 def test_staged_sliced_form_at_baseline_config_3_size(gpu, monkeypatch, staged):
     """The staged variant of the sliced form (a workgroup owns whole sorting windows, collects their row sums in LDS and stores a window as one run; spmv_layout.h) only
@@ -138,14 +159,8 @@ def test_staged_sliced_form_at_baseline_config_3_size(gpu, monkeypatch, staged):
     both precisions, with a few dense rows (long rows INSIDE staged windows, summed by the window's owner) and an empty stretch of constraint rows, staged and
     QPS_SPMV_STAGED=0 (the lane-by-lane stores) on the same matrices."""
     monkeypatch.setenv("QPS_SPMV_STAGED", staged)                                # read per handle, at creation
-    rng = np.random.default_rng(77)
-    n, m = 50000, 100000
-    A = sp.random(m, n, density=1e-3, random_state=rng, format="lil", dtype=np.float64)
-    for r in (0, 2111, 2112, 54321, m - 1):
-        A[r, :] = sp.random(1, n, density=0.05, random_state=rng, dtype=np.float64)   # ~2500 entries: ~360 per column block (> SLONG)
-    A[60000:63000, :] = 0
-    A = sp.csc_matrix(A)
-    P = spd_companion(rng, n, 3)
+    P, A = c3_size_matrices()
+    rng = np.random.default_rng(79)
     for dtype in ("f64", "f32"):
         check_operator(gpu, P, A, rng, f"c3-size staged={staged}", dtype, monkeypatch, "1")
 
