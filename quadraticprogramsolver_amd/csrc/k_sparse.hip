@@ -1495,11 +1495,18 @@ template <typename T> struct SparseProxQpSolver : ProxQpBase {
         double rho = p.rho; const double sigma = p.sigma;
         int converged = 0, conv_it = p.numIterations; double resP = INFINITY, resD = INFINITY, rho_rep = p.rho;
         ss->ldl_prepare(rho, sigma, true);                                                          // UpdateDecomposition! (ProxQP.jl:131, :201-206)
+        const char* gxs = getenv("QPS_PROXQP_GX_SOLVE");                                            // read per solve
+        const bool gx_product = !(gxs && gxs[0] == '1');
         for (int ii = 1; ii <= p.numIterations; ++ii) {                                             // :135
             const bool check = (ii % p.numItrConv == 0);
             if (mtot > 0) hipLaunchKernelGGL((pqrows::k_pq_h<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, slack, hvec);
-            ss->ldl->solve(x, ss->q, hvec, dual, rho, sigma, xx, v);                                // CalculateRhs! + UpdateX! (:208-225); v = G x
+            ss->ldl->solve(x, ss->q, hvec, dual, rho, sigma, xx, v);                                // CalculateRhs! + UpdateX! (:208-225)
             std::swap(x, xx);
+            // `mA * vX`, `mC * vX` of the row updates (:230-248) by the product itself, as the reference forms them -- not the G x that falls out of the KKT solve
+            // (same value up to the un-refined, un-pivoted solve's error).  The reference's check (:264-266) repeats the SAME product, so `C x - d + s` with
+            // s = d - C x cancels EXACTLY on rows with z = 0; a primal residual of exactly 0 sends rho to its lower clamp (:281-283), a residual of 1e-16 to
+            // rho * 1e-4: with G x from the solve in the updates and from the product in the check the two runs part for good (ProxQP fuzz, seed 43, case 184).
+            if (mtot > 0 && gx_product) ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);
             if (mtot > 0) hipLaunchKernelGGL((pqrows::k_pq_update<T>), g1(mtot), dim3(256), 0, st, (int)me, mtot, g, v, dual, slack, (T)rho);   // :227-249
             if (check) {                                                                            // :151  CheckConvergence! :252-298
                 ss->spmv(ss->P, x, X1, T(1), nullptr, T(0), nullptr, T(0), nullptr);                // :261
@@ -1509,9 +1516,9 @@ template <typename T> struct SparseProxQpSolver : ProxQpBase {
                     ss->spmv(ss->At, de, X2, T(1), nullptr, T(0), nullptr, T(0), nullptr);          // A'y (:262)
                     ss->spmv(ss->At, di, X3, T(1), nullptr, T(0), nullptr, T(0), nullptr);          // C'z (:263)
                 }
-                // mA * vX, mC * vX of CheckConvergence! (:264-265) by the product itself: the `v` the row updates used came back with the un-refined,
-                // un-pivoted L D L' solve, whose error (rho clamped up to 1e5, fp32) would otherwise go straight into the reported primal residual
-                if (mtot > 0) ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);
+                // mA * vX, mC * vX of CheckConvergence! (:264-265): the product the row updates have just used (QPS_PROXQP_GX_SOLVE=1: recomputed here -- the
+                // solve's G x carries the error of the un-refined L D L' solve, which must not go into the reported primal residual)
+                if (mtot > 0 && !gx_product) ss->spmv(ss->A, x, v, T(1), nullptr, T(0), nullptr, T(0), nullptr);
                 HIPC(hipMemsetAsync(slots, 0, 16 * sizeof(unsigned long long), st));
                 hipLaunchKernelGGL((pqrows::k_pq_norms<T>), dim3(64), dim3(256), 0, st, (int)n, (int)me, mtot, v, g, slack, X1, X2, X3, ss->q, slots);
                 HIPC(hipMemcpyAsync(slots_host, slots, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));

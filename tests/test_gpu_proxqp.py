@@ -167,6 +167,26 @@ def test_sparse_iterates_and_report_match_oracle(gpu, po, n, me, mi, feasible, a
             assert abs(rg["DualResidual"] - rr["DualResidual"]) <= 1e-7 * max(1.0, rr["DualResidual"])
 
 
+def test_sparse_row_updates_use_the_product_so_an_exactly_zero_primal_residual_stays_zero(gpu, po):
+    """ProxQP.jl:230-248 form `mC * vX` for the s / z updates and :264-266 repeat the same product in the check, so on rows with z = 0 the residual
+    `C x - d + s`, s = d - C x, cancels EXACTLY.  On this problem (ProxQP fuzz, seed 43, case 184) that happens at the second check with rho at its upper
+    clamp: resRatio = 0 sends rho to 1e-5 (:281-283) and the reference does not converge within 400 iterations.  A device run whose row updates take G x
+    from the KKT solve and whose check takes it from the product sees 1e-16 there, goes to rho * 1e-4 instead and converges: a different report from the
+    same inputs.  With the product in both places the cancellation is exact on the device too."""
+    P, q, A, b, C, d = make_sparse_problem(5, 0, 5, 500 + 184, density=0.3, feasible=True)
+    Pd, Ad, Cd = P.toarray(), A.toarray(), C.toarray()
+    kw = dict(numIterations=400, ρ=200.0, σ=1e-2, adptΡ=True, τ=10.0, numItrConv=50)
+    ref = po.ProxQP.from_problem(Pd, q, Ad, b, Cd, d)
+    rr = po.SolveQuadraticProgramProxQP(ref, **kw)
+    assert not rr["Converged"] and rr["ρ"] < 1.0                                  # the restatement's path through the lower clamp
+    init = po.ProxQP.from_problem(Pd, q, Ad, b, Cd, d)
+    with gpu.ProxQP(P, q, A, b, C, d, init.vX, init.vY, init.vZ, init.vS) as prob:
+        rg = gpu.SolveQuadraticProgramProxQP(prob, **kw)
+        assert rg["Converged"] == rr["Converged"] and rg["Iterations"] == rr["Iterations"]
+        assert abs(rg["ρ"] - rr["ρ"]) <= 1e-8 * rr["ρ"]
+        assert rel(prob.vX, ref.vX) <= 1e-8 and rel(prob.vZ, ref.vZ) <= 1e-7 and rel(prob.vS, ref.vS) <= 1e-8
+
+
 def test_sparse_kkt_initialisation_with_singular_p_and_loud_failure(gpu):
     """ProxQP.jl:95-115 solves [P A'; A 0] \\ [-q; b] with an LU: a positive SEMI-definite P is fine as long as the KKT matrix is non-singular (P positive
     definite on the null space of A).  The device factorises [P + delta I, A'; A, -delta I] and refines against the unshifted system, so that case
