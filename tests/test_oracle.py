@@ -102,6 +102,30 @@ def test_cg_plugins_reach_the_same_solution(c_oracle, np_oracle):
     assert np.abs(xn - x0).max() <= 1e-4
 
 
+def test_bit_exact_stagnation_with_zero_tolerances_depends_on_the_last_bit(c_oracle, np_oracle):
+    """With ϵAbs = ϵRel = 0 (every fixed-K run of BASELINE) ϵAdmm = 0 too (SolveQuadraticProgram.jl:34) and the stall test `norm(vX - vXP, Inf) <= ϵAdmm` (:105)
+    fires only when an iteration reproduces x AND z bit for bit.  Whether, and at which check, a converged sequence does that is decided by the last bit of every
+    operation: on this 3 x 1 problem (C-ABI fuzz, seed 53, case 166) the C restatement stops at iteration 125 with convAdmm, the numpy restatement of the same
+    statements -- and the device -- keep moving in the last place and return convNumItr, with x equal to 1e-16.  Julia's own arithmetic (OpenBLAS products, LLVM's
+    choice of contractions) is a third one.  The differential tools therefore accept a {convNumItr, convAdmm} pair when both tolerances are 0 and x agrees to rounding;
+    with ϵ > 0 the flags are compared for equality everywhere."""
+    P = np.array([[1.3775070137028265, -0.21141185522807113, 0.4967376679481899],
+                  [-0.21141185522807113, 12.473155853106338, 2.697228866433424],
+                  [0.4967376679481899, 2.697228866433424, 7.939093655973197]])
+    q = np.array([-0.434949823784708, 0.09376780028830319, 0.16370646140595482])
+    A = np.array([[-0.6956942730907582, 0.7292757028075237, 0.38459302881288804]])
+    l, u = np.array([-0.8524452997444086]), np.array([0.5148046152533186])
+    xc, io = c_oracle.solve(P, q, A, l, u, numIterations=400, epsAbs=0.0, epsRel=0.0, rho=10.0, adptRho=False)
+    xn = np.zeros(3); info = {}
+    fn = np_oracle.SolveQuadraticProgramRefLoop(xn, P, q, A, l, u, np_oracle.RedCholInit, np_oracle.RedChol, numIterations=400, ϵAbs=0.0, ϵRel=0.0, ρ=10.0,
+                                                adptΡ=False, info=info)
+    assert np.abs(xc - xn).max() <= 1e-15                                         # the same answer ...
+    flags = {int(io["convFlag"]), int(fn)}
+    assert flags <= {1, 2}                                                        # ... by convNumItr or by a bit-exact stall, never by the residual test (`<` 0)
+    if flags == {1, 2}:                                                           # (as observed here; a different libm / BLAS may make both stall or neither)
+        assert min(io["iterations"], info["iterations"]) < 400
+
+
 def test_both_termination_tests_run_and_stall_overrides(np_oracle):
     """SolveQuadraticProgram.jl:102-107: the second `if` is not an `else`; convAdmm wins when both hold; `<` vs `<=`."""
     n = 3

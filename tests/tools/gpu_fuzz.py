@@ -56,11 +56,17 @@ for c in range(cases):
         dev = np.abs(x - xo).max() / max(1.0, np.abs(xo).max())
         same = (int(flag) == io["convFlag"] and info["iterations"] == io["iterations"]) if dtype == "f64" else True
         loose = 1e-5 if (adpt or kind == "cg") and dtype == "f64" else tol
+        note = ""
+        if not same and eps == 0.0 and dev <= 1e-14 and {int(flag), io["convFlag"]} == {1, 2}:
+            # eps = 0 => epsAdmm = 0 (SolveQuadraticProgram.jl:34): the stall test (:105) fires only on a bit-exact repeat of x and z, and whether a converged sequence
+            # produces one is decided by the last bit of every operation (seed 53 case 166; tests/test_oracle.py::test_bit_exact_stagnation_...: the C and the numpy
+            # restatement differ in exactly this way).  Same x to rounding, flags {convNumItr, convAdmm}: accepted and named.
+            same = True; note = f" [bit-exact stall is rounding-dependent at eps = 0: flag {int(flag)}/{io['convFlag']} its {info['iterations']}/{io['iterations']}]"
         if not (dev <= loose) or not same or not np.all(np.isfinite(x)):
             bad += 1
             print(f"MISMATCH {tag}: dev={dev:.2e} flag {int(flag)}/{io['convFlag']} its {info['iterations']}/{io['iterations']} ref {info.get('numRefactor')}/{io.get('numRefactor')}", flush=True)
         else:
-            print(f"ok {tag}: dev={dev:.1e}", flush=True)
+            print(f"ok {tag}: dev={dev:.1e}{note}", flush=True)
     except Exception as e:
         bad += 1
         print(f"ERROR {tag}: {type(e).__name__}: {e}", flush=True)
