@@ -125,16 +125,35 @@ def base_line(args, cfg, info, value, tmax, scaling, metric="ADMM iterations/sec
             "dtype": cfg["dtype"], "data": "synthetic", "config": {"workload": cfg["label"], "n": cfg["n"], "m": cfg["m"], "admm_iterations_per_step": args.iters}}
 
 
-def csrc_digest():
-    """Identity of the kernel sources the running library was built from: sha256 over the sorted files of csrc/ and include/qps.h.  The PMC
-    summaries under profiles/ carry the digest of the tree they were measured on; a figure measured on other sources is not reported."""
+# Translation units that hold only the sparse solvers (their own object files: no kernel of a dense handle is compiled from them).  A summary of a DENSE config
+# measured on a tree that differs from the running one in these files alone is still this build's figure: the object files with the dense kernels were built
+# from byte-identical sources, headers and flags.  Such a match is reported as what it is (`traffic_match`: "dense translation units").
+SPARSE_ONLY_UNITS = ("k_sparse.hip", "k_ldl.hip", "ldl_symbolic.cpp", "spmv_layout.cpp")
+DENSE_CONFIGS = ("c1", "c2", "c2_trsv1024", "c4", "c5")
+
+
+def csrc_digest(exclude=(), read=None, listing=None):
+    """Identity of the kernel sources the running library was built from: sha256 over the sorted files of csrc/ and include/qps.h (`exclude`: file names left out).
+    The PMC summaries under profiles/ carry the digest of the tree they were measured on; a figure measured on other sources is not reported.
+    `read` / `listing` let a tool hash another tree (a git commit) with the same rule."""
     h = hashlib.sha256()
     base = os.path.join(ROOT, "quadraticprogramsolver_amd", "csrc")
-    files = sorted(f for f in os.listdir(base) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    names = os.listdir(base) if listing is None else listing
+    read = read or (lambda rel: open(os.path.join(base, rel), "rb").read())
+    files = sorted(f for f in names if (f.endswith((".hip", ".h", ".cpp")) or f == "Makefile") and f not in exclude)
     for f in files + [os.path.join("..", "..", "include", "qps.h")]:
         h.update(os.path.basename(f).encode() + b"\0")
-        h.update(open(os.path.join(base, f), "rb").read())
+        h.update(read(f))
     return h.hexdigest()[:16]
+
+
+def digest_matches(meta, config):
+    """None when the summary's build is not the running one; else how it matches: "whole tree", or -- dense configs only -- "dense translation units"."""
+    if meta.get("csrc_sha16") == csrc_digest():
+        return "whole tree"
+    if config in DENSE_CONFIGS and meta.get("csrc_dense_sha16") and meta.get("csrc_dense_sha16") == csrc_digest(exclude=SPARSE_ONLY_UNITS):
+        return "dense translation units (the running tree differs from the measured one at most in " + ", ".join(SPARSE_ONLY_UNITS) + ": sparse solvers only)"
+    return None
 
 
 def build_head():
@@ -164,6 +183,8 @@ def roofline_of(kernel_label, seconds, launches, algo_bytes_per_launch, traffic,
     r["traffic_head"] = LAST_TRAFFIC_META.get("head")            # build the PMC passes ran on (null: no matching summary)
     r["traffic_csrc_sha16"] = LAST_TRAFFIC_META.get("csrc_sha16")
     r["running_csrc_sha16"] = csrc_digest()
+    if LAST_TRAFFIC_META.get("match"):
+        r["traffic_match"] = LAST_TRAFFIC_META["match"]
     if LAST_TRAFFIC_META.get("stale"):
         r["traffic_note"] = LAST_TRAFFIC_META["stale"]
     if extra:
@@ -186,7 +207,7 @@ def rocprof_stats(config):
             meta = json.load(open(f[:-4] + ".meta.json"))
         except Exception:
             continue
-        if meta.get("csrc_sha16") != csrc_digest():
+        if not digest_matches(meta, config):
             continue
         rows = {}
         for r in csv.DictReader(open(f)):
@@ -596,12 +617,13 @@ def pmc_traffic(config, kernel_regex):
     try:
         d = json.load(open(files[-1]))
         meta = d.get("_meta") or {}
-        if meta.get("csrc_sha16") != csrc_digest():
+        how = digest_matches(meta, config)
+        if not how:
             # measured on other kernel sources (or before summaries carried their build): not this build's traffic
             LAST_TRAFFIC_META.update(stale=f"profiles/{os.path.basename(files[-1])} was measured on csrc {meta.get('csrc_sha16')} (HEAD {meta.get('head')}), "
                                            f"the running build is csrc {csrc_digest()}: traffic not reported")
             return None, None
-        LAST_TRAFFIC_META.update(head=meta.get("head"), csrc_sha16=meta.get("csrc_sha16"))
+        LAST_TRAFFIC_META.update(head=meta.get("head"), csrc_sha16=meta.get("csrc_sha16"), match=how)
         best = None
         for name, v in d.items():
             if name != "_meta" and re.search(kernel_regex, name) and (best is None or v.get("launches", v.get("launches_sampled", 0)) > best[1].get("launches", best[1].get("launches_sampled", 0))):

@@ -6,7 +6,7 @@ The summary carries `_meta`: the git HEAD and the digest of the kernel sources i
 when that digest is the running build's)."""
 import collections, csv, json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from bench import build_head, csrc_digest
+from bench import build_head, csrc_digest, SPARSE_ONLY_UNITS
 
 
 def load(path):
@@ -18,7 +18,7 @@ def load(path):
 
 
 f, w = load(sys.argv[1]), load(sys.argv[2])
-out = {"_meta": {"head": build_head(), "csrc_sha16": csrc_digest(), "command": sys.argv[4] if len(sys.argv) > 4 else None,
+out = {"_meta": {"head": build_head(), "csrc_sha16": csrc_digest(), "csrc_dense_sha16": csrc_digest(exclude=SPARSE_ONLY_UNITS), "command": sys.argv[4] if len(sys.argv) > 4 else None,
                  "method": "two separate rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, --kernel-trace only); hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE"}}
 for k in sorted(f, key=lambda k: -sum(f[k])):
     if not k.startswith("k_"): continue
