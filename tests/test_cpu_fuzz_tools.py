@@ -17,7 +17,7 @@ def run_tool(name, cases, seed):
     return out.stdout
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("cpu_fuzz_layouts.py", 40, 5), ("cpu_fuzz_ldl_symbolic.py", 60, 5)])
+@pytest.mark.parametrize("tool,cases,seed", [("cpu_fuzz_layouts.py", 40, 5), ("cpu_fuzz_ldl_symbolic.py", 60, 5), ("cpu_fuzz_csc.py", 25, 5)])
 def test_layout_and_symbolic_tools_find_nothing(tool, cases, seed):
     text = run_tool(tool, cases, seed)
     assert re.search(rf"^{cases} cases, 0 bad", text, re.M), text[-1500:]
